@@ -1,0 +1,57 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "overiva_*.npz")))
+
+
+def golden_ids():
+    return [os.path.basename(p)[len("overiva_"):-len(".npz")] for p in golden_files()]
+
+
+@pytest.fixture(params=golden_files(), ids=golden_ids())
+def golden(request):
+    """one committed fixture = inputs + outputs of the real reference (tests/golden/make_golden.py)"""
+    with np.load(request.param) as d:
+        g = {k: d[k] for k in d.files}
+    g["_id"] = os.path.basename(request.param)[len("overiva_"):-len(".npz")]
+    return g
+
+
+AMP_LIMIT = 1e3
+
+
+def chaotic(g, model, n_iter):
+    """True when the REFERENCE ITSELF is ill-conditioned for this (fixture, model, n_iter).
+
+    make_golden.py stores ``amp_<model>_<n_iter>`` = relative change of the real reference's
+    complex128 result under a 1e-12 relative perturbation of X, divided by 1e-12.  The laplace
+    model stays at amp ~ 1..10 everywhere; the gauss model on these small-F fixtures blows up to
+    1e7..1e12 between 5 and 20 iterations (an activation r = sum_f |y|^2 / F over a handful of
+    bins gets arbitrarily close to 0).  Nothing can be pinned tighter than amp * rounding, so
+    such entries are skipped rather than compared at a meaningless tolerance."""
+    key = f"amp_{model}_{n_iter}"
+    return key in g and float(g[key]) > AMP_LIMIT
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False

@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator.  Runs ONLY in the build container (needs /root/reference).
+
+Imports the real reference (``/root/reference/overiva.py`` / ``auxiva_pca.py``,
+unmodified, read-only) and records inputs and outputs of its hot path as small
+``.npz`` fixtures next to this file.  Nothing here travels as code to the GPU box
+except this script itself; the fixtures are data (inputs + expected outputs).
+
+Two shims are needed to import the reference in this image:
+
+1. ``pyroomacoustics`` is not installed and ``overiva.py:25`` imports
+   ``projection_back`` from it.  A stub module provides the restated formula
+   (``oracle/overiva_oracle.py::projection_back`` -- parity unpinned, see there).
+   With ``proj_back=False`` the stub is never called.
+2. ``overiva.py:182`` calls ``np.linalg.solve(A, b)`` with a stack-of-vectors ``b``
+   which NumPy >= 2 rejects; the module-global ``np`` of the imported reference is
+   rebound to a proxy that restores the NumPy-1 behaviour.  The file is untouched.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from oracle.overiva_oracle import projection_back, synth_iid, synth_mixture  # noqa: E402
+
+REFERENCE = "/root/reference"
+
+
+def import_reference():
+    pra = types.ModuleType("pyroomacoustics")
+    bss = types.ModuleType("pyroomacoustics.bss")
+    bss.projection_back = projection_back
+    pra.bss = bss
+    sys.modules["pyroomacoustics"] = pra
+    sys.modules["pyroomacoustics.bss"] = bss
+    sys.path.insert(0, REFERENCE)
+    import overiva as ref_overiva
+    import auxiva_pca as ref_pca
+
+    class _Linalg:
+        def __getattr__(self, name):
+            return getattr(np.linalg, name)
+
+        @staticmethod
+        def solve(a, b):
+            a = np.asarray(a)
+            b = np.asarray(b)
+            if b.ndim == a.ndim - 1:
+                return np.linalg.solve(a, b[..., None])[..., 0]
+            return np.linalg.solve(a, b)
+
+    class _Np:
+        linalg = _Linalg()
+
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+    ref_overiva.np = _Np()
+    return ref_overiva, ref_pca
+
+
+# (name, T, F, M, K)
+CASES = [
+    ("a", 40, 5, 3, 1),
+    ("b", 50, 9, 4, 2),
+    ("c", 64, 11, 4, 4),
+    ("d", 80, 20, 8, 2),
+    ("e", 64, 4, 16, 16),
+    ("f", 48, 6, 2, 2),
+    ("g", 72, 7, 6, 3),
+]
+N_ITERS = (0, 1, 2, 5, 20)
+
+
+def make_input(family, T, F, M, K, seed):
+    if family == "iid":
+        return synth_iid(T, F, M, seed=seed)
+    return synth_mixture(T, F, M, max(K, 1), seed=seed)
+
+
+def trace_intermediates(ref_overiva, X, K, n_iter, model):
+    """Snapshot V, r_inv, W_hat at every (epoch, s) right after overiva.py:179 executed
+    (i.e. when line 181 is about to run), and W_hat at the end of each source update."""
+    snaps = []
+    target = ref_overiva.overiva.__code__
+
+    def tracer(frame, event, arg):
+        if frame.f_code is not target:
+            return None
+
+        def local(frame, event, arg):
+            if event == "line" and frame.f_lineno == 181:
+                loc = frame.f_locals
+                snaps.append(dict(epoch=loc["epoch"], s=loc["s"], V=loc["V"].copy(),
+                                  r_inv=loc["r_inv"].copy(), W_hat=loc["W_hat"].copy()))
+            return local
+
+        return local
+
+    sys.settrace(tracer)
+    try:
+        Y, W = ref_overiva.overiva(X, n_src=K, n_iter=n_iter, proj_back=False, model=model,
+                                   return_filters=True)
+    finally:
+        sys.settrace(None)
+    return snaps, Y, np.array(W)
+
+
+def main():
+    ref_overiva, ref_pca = import_reference()
+    total = 0
+    for name, T, F, M, K in CASES:
+        for family in ("iid", "mix"):
+            seed = 1000 + 7 * len(name) + ord(name) + (0 if family == "iid" else 500)
+            X64 = make_input(family, T, F, M, K, seed)
+            out = {"X": X64, "T": T, "F": F, "M": M, "K": K}
+            nonfinite = []
+            pert = 1.0 + 1e-12 * np.random.default_rng(seed + 2).standard_normal(X64.shape)
+            for dt_name, X in (("c64", X64), ("c128", X64.astype(np.complex128))):
+                for model in ("laplace", "gauss"):
+                    for n_iter in N_ITERS:
+                        Y, W = ref_overiva.overiva(X.copy(), n_src=K, n_iter=n_iter, proj_back=False,
+                                                   model=model, return_filters=True)
+                        key = f"{dt_name}_{model}_{n_iter}"
+                        assert Y.dtype == X.dtype and W.dtype == X.dtype
+                        if not (np.all(np.isfinite(W)) and np.all(np.isfinite(Y))):
+                            # the reference itself diverged (seen for complex64 / gauss /
+                            # determined mixtures): nothing to pin, remember the key
+                            nonfinite.append(key)
+                            continue
+                        out[f"W_{key}"] = np.ascontiguousarray(W)
+                        if dt_name == "c128":
+                            # conditioning of the reference itself: relative change of its W under a
+                            # 1e-12 relative perturbation of X, divided by 1e-12
+                            _, Wp = ref_overiva.overiva(X * pert, n_src=K, n_iter=n_iter, proj_back=False,
+                                                        model=model, return_filters=True)
+                            amp = np.linalg.norm(Wp - W) / np.linalg.norm(W) / 1e-12
+                            out[f"amp_{model}_{n_iter}"] = np.float64(amp)
+                        if n_iter == 20 and (dt_name == "c128" or model == "laplace"):
+                            out[f"Y_{key}"] = Y
+                    # proj_back=True epilogue + callback payloads (epochs 0 and 10)
+                    if dt_name == "c64" and model == "gauss":
+                        continue
+                    got = []
+                    Ypb = ref_overiva.overiva(X.copy(), n_src=K, n_iter=12, proj_back=True, model=model,
+                                              callback=lambda y: got.append(np.array(y)))
+                    out[f"Ypb_{dt_name}_{model}_12"] = Ypb
+                    if dt_name == "c128":
+                        Yp = ref_overiva.overiva(X * pert, n_src=K, n_iter=12, proj_back=True, model=model)
+                        out[f"amp_{model}_12"] = np.float64(np.linalg.norm(Yp - Ypb) / np.linalg.norm(Ypb) / 1e-12)
+                    if dt_name == "c128" and model == "laplace":
+                        out[f"cb0_{dt_name}_{model}"] = got[0]
+                        out[f"cb10_{dt_name}_{model}"] = got[1]
+                    assert len(got) == 2
+            X128 = X64.astype(np.complex128)
+            # warm start: W0 broadcasting to (F, M, K)  (overiva.py:116-117)
+            rng = np.random.default_rng(seed + 1)
+            W0 = (np.eye(M, K)[None] + 0.1 * (rng.standard_normal((F, M, K))
+                                               + 1j * rng.standard_normal((F, M, K))))
+            out["W0"] = W0
+            Y, W = ref_overiva.overiva(X128.copy(), n_src=K, n_iter=3, proj_back=False, W0=W0,
+                                       return_filters=True)
+            out["W_w0_c128_laplace_3"] = np.ascontiguousarray(W)
+            # init_eig (compare up to per-column phase: eigvec phase is LAPACK-dependent)
+            Y, W = ref_overiva.overiva(X128.copy(), n_src=K, n_iter=3, proj_back=False, init_eig=True,
+                                       return_filters=True)
+            out["W_eig_c128_laplace_3"] = np.ascontiguousarray(W)
+            out["Y_eig_c128_laplace_3"] = Y
+            # default n_src (determined AuxIVA on all channels)
+            Y, W = ref_overiva.overiva(X128.copy(), n_iter=2, proj_back=False, return_filters=True)
+            out["W_det_c128_laplace_2"] = np.ascontiguousarray(W)
+            # auxiva_pca (auxiva_pca.py:63-92); needs proj_back kw, returns Y only
+            Ypca = ref_pca.auxiva_pca(X128.copy(), n_src=K, n_iter=5, proj_back=True, model="laplace")
+            out["Ypca_c128_laplace_5"] = Ypca
+            # per-(epoch, source) intermediates, c128, two epochs
+            if name in ("b", "d", "g", "c"):
+                for model in ("laplace", "gauss"):
+                    snaps, Y, W = trace_intermediates(ref_overiva, X128.copy(), K, 2, model)
+                    assert len(snaps) == 2 * K
+                    for sn in snaps:
+                        tag = f"im_{model}_e{sn['epoch']}_s{sn['s']}"
+                        out[f"{tag}_V"] = sn["V"]
+                        out[f"{tag}_rinv"] = sn["r_inv"]
+                        out[f"{tag}_What"] = sn["W_hat"]
+                    out[f"im_{model}_Wfinal"] = W
+            out["nonfinite"] = np.array(nonfinite, dtype="U32")
+            path = os.path.join(HERE, f"overiva_{name}_{family}.npz")
+            np.savez_compressed(path, **out)
+            sz = os.path.getsize(path)
+            total += sz
+            print(f"{path}: {len(out)} arrays, {sz / 1024:.0f} KiB")
+    print(f"total {total / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
