@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the AuxIVA / OverIVA iteration hot path on MI355X.
+
+Metric (BASELINE.json): AuxIVA iterations/sec at 2048 bins x 4000 frames x 8 mics / 2 sources
+(OverIVA, laplace), synthetic complex64 STFT, at 1/2/4/8 GPUs.  One "step" = one iteration of the
+loop body reference overiva.py:138-190; prologue and epilogue are outside the timed region and X is
+resident in HBM when it starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 shards the 2048 bins over the ranks (strong scaling: the problem is fixed) with one RCCL
+all-gather of the (T, K) partial source powers per iteration.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- weighted-covariance pass: algorithmic bytes (8TFM + 4TK + 8FKM^2) /
+                  average kernel duration measured with HIP events on the kernel's own stream
+  cpu_baseline -- the oracle's reference-faithful NumPy restatement of overiva.py timed on this
+                  box's host cores on a bounded sample (N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+T, F, M, K = 4000, 2048, 8, 2
+MODEL = "laplace"
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+WORKLOAD = f"OverIVA {F} bins x {T} frames x {M} mics / {K} src, {MODEL}, complex64 (BASELINE.json configs[2])"
+
+
+def cov_algorithmic_bytes(t, f, m, k):
+    """read X once + read r_inv + write V"""
+    return 8 * t * f * m + 4 * t * k + 8 * f * k * m * m
+
+
+def synth_x_device(torch, device, f0, f1):
+    """The iid complex64 workload, generated on the device (seeded per bin so that any sharding of
+    the bins sees the same tensor)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(1234)
+    x = torch.randn((T, F, M, 2), generator=g, device=device, dtype=torch.float32)
+    x = x[:, f0:f1].contiguous()
+    return torch.view_as_complex(x)
+
+
+def cpu_baseline():
+    """Reference-faithful NumPy restatement (oracle) on a bounded sample: 128 of the 2048 bins, all
+    4000 frames, 8 mics / 2 src; per-iteration time = (t(3 its) - t(1 it)) / 2 so the prologue
+    cancels; work is linear in bins, so it/s at 2048 bins = it/s on the sample * 128 / 2048."""
+    from oracle import overiva_oracle as orc
+
+    fs = 128
+    X = orc.synth_iid(T, fs, M, seed=0)
+    t0 = time.perf_counter()
+    orc.overiva_faithful(X, n_src=K, n_iter=1, proj_back=False, model=MODEL)
+    t1 = time.perf_counter()
+    orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=False, model=MODEL)
+    t2 = time.perf_counter()
+    per_iter = max(((t2 - t1) - (t1 - t0)) / 2.0, 1e-9)
+    its = (1.0 / per_iter) * fs / F
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    except Exception:
+        pass
+    return {"value": its, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "sample": f"oracle.overiva_faithful (NumPy, complex64 in / float64 r like overiva.py) on {fs} of {F} bins x "
+                      f"{T} frames x {M} mics / {K} src, iterations 2-3, scaled by {fs}/{F}; "
+                      f"{per_iter:.3f} s per iteration on the sample"}
+
+
+def run_single(args):
+    import torch
+
+    import overiva_amd as oa
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    X = synth_x_device(torch, dev, 0, F)
+    torch.cuda.synchronize()
+    plan = oa.Plan(T, F, M, K, MODEL, device=0)
+    plan.set_x_device(X.data_ptr(), keepalive=X)
+    plan.covariance()
+    plan.set_w(None)
+    if args.graph:
+        plan.use_graph(True)
+    plan.iterate(args.warmup)
+    plan.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan.iterate(args.steps)
+    plan.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the same K steps again with every kernel bracketed by HIP events on the plan's stream
+    total_ms, stages = plan.iterate_timed(args.steps, per_kernel=True)
+    W = plan.get_w()
+    assert np.all(np.isfinite(W))
+    cov_ms = stages["weighted_cov"] / args.steps
+    bytes_cov = cov_algorithmic_bytes(T, F, M, K)
+    achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "cov_kernel<8,2> (weighted spatial covariance, overiva.py:179)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
+                "stage_ms_per_step": {k: v / args.steps for k, v in stages.items()},
+                "event_timed_ms_per_step": total_ms / args.steps, "cov_splits": plan.cov_splits()}
+    plan.close()
+    out = result_line(args, 1, dt)
+    out["roofline"] = roofline
+    out["cpu_baseline"] = cpu_baseline() if not args.no_cpu else None
+    if out["cpu_baseline"]:
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def run_sharded(args):
+    import torch
+    import torch.distributed as dist
+
+    from overiva_amd.sharded import HipEngine, shard_bounds
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    rank = int(os.environ.setdefault("RANK", "0"))
+    world = int(os.environ.setdefault("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev)
+    b = shard_bounds(F, world)
+    f0, f1 = b[rank], b[rank + 1]
+    X = synth_x_device(torch, dev, f0, f1)
+    torch.cuda.synchronize()
+    eng = HipEngine(T, f1 - f0, M, K, MODEL, F, local)
+    stream = eng.stream
+    with eng.stream_ctx():
+        eng.set_x_device(X.data_ptr(), keepalive=X)
+        eng.covariance()
+        eng.set_w(None)
+        p_local = eng.exchange_buffer()
+        p_all = eng.new_gather_buffer(world)
+
+        def step():
+            eng.power()
+            dist.all_gather_into_tensor(p_all, p_local)
+            eng.update(p_all)
+
+        for _ in range(args.warmup):
+            step()
+        stream.synchronize()
+        graph = None
+        if args.graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    step()
+                graph.replay()
+                stream.synchronize()
+            except Exception as e:  # capture of the collective not supported: stay eager
+                if rank == 0:
+                    print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); eager", file=sys.stderr)
+                graph = None
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                step()
+        stream.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    dist.barrier()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    W = eng.get_w()
+    assert np.all(np.isfinite(W))
+    eng.close()
+    out = result_line(args, world, float(tmax.item()))
+    out["config"]["graph"] = graph is not None
+    dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def result_line(args, n_gpus, seconds):
+    return {
+        "metric": "AuxIVA iterations/sec (2048 bins x 4000 frames x 8 mics)",
+        "value": args.steps / seconds,
+        "unit": "iterations/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": seconds / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": WORKLOAD, "bins": F, "frames": T, "mics": M, "sources": K, "model": MODEL,
+                   "parallelism": f"bins sharded over {n_gpus} GPU(s), one RCCL all-gather of (T,K) f32 per iteration"
+                   if n_gpus > 1 else "single GPU", "graph": bool(args.graph)},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graph", type=int, default=1, help="replay iterations from a captured graph (default on)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path even with one rank (exercises RCCL + graph capture on 1 GPU)")
+    args = ap.parse_args()
+    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_sharded:
+        out = run_sharded(args)
+    else:
+        out = run_single(args)
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

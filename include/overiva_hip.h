@@ -1,0 +1,151 @@
+/*
+ * overiva_hip.h -- C ABI of liboveriva_hip.so: the MI355X (gfx950) implementation of the
+ * AuxIVA / OverIVA iteration hot path of onolab-tmu/overiva.
+ *
+ * The reference has no FFI: its boundary for this path is the Python call
+ *     overiva(X, n_src, n_iter, proj_back, W0, model, init_eig, return_filters, callback)
+ * (reference overiva.py:28-38) and auxiva_pca(X, n_src, **kwargs) (auxiva_pca.py:30).
+ * The entry points below are what a ctypes binding placed inside those two functions binds;
+ * each one names the reference statements it replaces.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative OIVA_ERR_* otherwise;
+ *     oiva_last_error() then returns a thread-local message.
+ *   - complex arrays are interleaved float32 (re, im) = numpy complex64, C order.
+ *   - "host" pointers are ordinary process memory, "dev" pointers are HIP device memory
+ *     on the plan's device.  The caller owns every buffer it passes in; the plan owns
+ *     everything it allocates; nothing returned by pointer outlives oiva_plan_destroy.
+ *   - one plan = one device + one stream + one contiguous range of frequency bins.
+ *     A plan is not thread-safe; distinct plans are independent.
+ *   - no call synchronises with the host except the ones documented to (copies to host,
+ *     oiva_plan_sync, the timing helpers).
+ */
+#ifndef OVERIVA_HIP_H
+#define OVERIVA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OIVA_OK 0
+#define OIVA_ERR_ARG (-1)      /* bad argument / unsupported shape */
+#define OIVA_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define OIVA_ERR_STATE (-3)    /* call order violated (e.g. iterate before X was set) */
+#define OIVA_ERR_NUMERIC (-4)  /* non-finite demixing matrix (numpy raises LinAlgError here) */
+
+#define OIVA_MODEL_LAPLACE 0   /* overiva.py:152-153, :161-163 */
+#define OIVA_MODEL_GAUSS 1     /* overiva.py:154-155, :164-167 */
+
+#define OIVA_MAX_CHANNELS 16
+
+typedef struct oiva_plan oiva_plan;
+
+/* library */
+int oiva_version(void);
+const char *oiva_last_error(void);
+int oiva_device_count(int *n);
+
+/*
+ * Plan life cycle.  T frames, F bins OWNED BY THIS PLAN, M channels, K sources (1 <= K <= M),
+ * F_total = number of bins of the whole problem (== F for a single-GPU run; > F when the bins are
+ * sharded over several plans/GPUs -- only the gauss model's 1/F (overiva.py:155) depends on it).
+ * stream: a hipStream_t to launch on (e.g. the framework's current stream), or NULL for a
+ * plan-owned stream.
+ */
+int oiva_plan_create(oiva_plan **out, int device, int T, int F, int M, int K, int model, int F_total,
+                     void *stream);
+int oiva_plan_destroy(oiva_plan *p);
+
+/*
+ * Input  X (T, F, M) complex64  -- replaces the copy at overiva.py:132 (the transpose there is
+ * not needed: kernels read the native (frames, bins, channels) order).
+ * _host: copies rows of F*M complex from a host array whose consecutive frames are
+ *        row_pitch_bytes apart (pass F_total*M*8 and a pointer to bin f0 to upload a bin shard
+ *        of a larger array; 0 means dense).  Synchronous.
+ * _dev : borrows a dense device array (no copy); it must stay valid while the plan uses it.
+ */
+int oiva_plan_set_x_host(oiva_plan *p, const void *X, long long row_pitch_bytes);
+int oiva_plan_set_x_dev(oiva_plan *p, const void *X_dev);
+
+/*
+ * Prologue, step 1: Cx[f] = (1/T) sum_t x x^H  (overiva.py:87).  Must follow set_x.
+ */
+int oiva_plan_covariance(oiva_plan *p);
+/* Cx as (F, M, M) complex64 on the host (used by the host-side init_eig path, overiva.py:106-109). */
+int oiva_plan_get_cx(oiva_plan *p, void *Cx_host);
+
+/*
+ * Prologue, step 2: demixing matrix  (overiva.py:89-123).
+ * W0_host: (F, M, K) complex64 or NULL for the identity start (overiva.py:113-114).
+ * Builds W_hat = [W | [J; -I]] with J from the orthogonality constraint (overiva.py:96-98,120-123).
+ */
+int oiva_plan_set_w(oiva_plan *p, const void *W0_host);
+
+/*
+ * n iterations of the loop body overiva.py:138-190 (demix -> activation r -> scale normalisation
+ * -> for every source: weighted covariance V, IP1 row solve, normalisation, J update).
+ * Only valid when the plan owns all bins (F == F_total).  Asynchronous.
+ */
+int oiva_plan_iterate(oiva_plan *p, int n);
+
+/*
+ * The same iteration cut at its one cross-bin dependency (overiva.py:152-155: r needs all bins),
+ * for bin-sharded multi-GPU runs:
+ *   oiva_plan_power   : p_local[t,k] = sum over THIS plan's bins of |w_k^H x|^2  -> (T, K) float32
+ *                       on the device (pointer from oiva_plan_power_buffer).
+ *   (caller all-gathers the p_local of all shards into parts_dev, (nparts, T, K) float32)
+ *   oiva_plan_update  : r from the fixed-order sum over parts, gamma, r_inv (overiva.py:152-173),
+ *                       then the per-bin part of the iteration (overiva.py:161-167 W scaling, :176-190).
+ */
+int oiva_plan_power(oiva_plan *p);
+int oiva_plan_power_buffer(oiva_plan *p, void **p_local_dev, long long *bytes);
+int oiva_plan_update(oiva_plan *p, const void *parts_dev, int nparts);
+
+/*
+ * Epilogue: Y = demix(X, W) as (T, F, K) complex64 (overiva.py:192-195), optionally scaled by
+ * projection back onto channel 0 (overiva.py:197-199; also the callback payload of :142-148).
+ * row_pitch_bytes as in set_x_host (0 = dense).  Synchronous.
+ */
+int oiva_plan_demix(oiva_plan *p, void *Y_host, long long row_pitch_bytes, int proj_back);
+/* W (F, M, K) complex64 -- the view returned at overiva.py:201-202.  Synchronous.
+ * Returns OIVA_ERR_NUMERIC if W holds a non-finite value (W is still copied out). */
+int oiva_plan_get_w(oiva_plan *p, void *W_host);
+
+int oiva_plan_sync(oiva_plan *p);
+
+/*
+ * Measurement.  Runs n iterations bracketed by HIP events on the plan's stream and, when
+ * per_kernel_ms is non-NULL, additionally brackets every kernel launch with events (eager
+ * launches) and returns the summed time of each stage in per_kernel_ms[0..4]:
+ * [0] demix+power pass, [1] r reduction, [2] r finalisation, [3] weighted-covariance pass,
+ * [4] per-bin update.  total_ms = wall time of the n iterations on the device.  Synchronous.
+ */
+int oiva_plan_iterate_timed(oiva_plan *p, int n, float *total_ms, float *per_kernel_ms);
+#define OIVA_N_STAGES 5
+
+/* Launch geometry of the weighted-covariance pass, for roofline accounting and tuning:
+ * get/set the number of frame splits (0 = library default). */
+int oiva_plan_get_cov_splits(oiva_plan *p, int *nsplit);
+int oiva_plan_set_cov_splits(oiva_plan *p, int nsplit);
+/* Replay the iteration from a captured hipGraph instead of eager launches (default off). */
+int oiva_plan_use_graph(oiva_plan *p, int enable);
+/* Arithmetic of the per-bin solves: 0 = float32 (default), 1 = float64. */
+int oiva_plan_set_precision(oiva_plan *p, int fp64_update);
+
+/*
+ * Test-only stage access (per-kernel parity tests call these through the same ABI).
+ * Stages run on the plan's current state; getters synchronise.
+ */
+int oiva_test_set_rinv(oiva_plan *p, const float *rinv_host /* (T,K) */);
+int oiva_test_get_rinv(oiva_plan *p, float *rinv_host /* (T,K) */, float *wscale_host /* (K) */);
+int oiva_test_run_weighted_cov(oiva_plan *p);                 /* overiva.py:179 for all K sources */
+int oiva_test_get_v(oiva_plan *p, void *V_host /* (K,F,M,M) complex64 */);
+int oiva_test_run_update(oiva_plan *p);                       /* overiva.py:181-190 for s = 0..K-1 */
+int oiva_test_get_what(oiva_plan *p, void *What_host /* (F,M,M) complex64 */);
+int oiva_test_set_what(oiva_plan *p, const void *What_host);
+int oiva_test_run_power(oiva_plan *p, float *p_host /* (T,K) summed over this plan's bins */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVERIVA_HIP_H */

@@ -1,0 +1,17 @@
+"""overiva_amd -- MI355X (gfx950) implementation of the AuxIVA / OverIVA iteration hot path of
+onolab-tmu/overiva behind the reference's own Python signatures.
+
+    from overiva_amd import overiva, auxiva_pca
+
+Host code is Python (as the reference is); all arithmetic on the path runs in hand-written HIP
+kernels reached through the C ABI of ``liboveriva_hip.so`` (``include/overiva_hip.h``).  There is
+no CPU fallback: without the built library the calls raise ``HipLibraryMissing``.
+"""
+from ._lib import HipError, HipLibraryMissing  # noqa: F401
+from .auxiva_pca import auxiva_pca  # noqa: F401
+from .overiva import get_device, overiva, set_device  # noqa: F401
+from .plan import Plan  # noqa: F401
+from .sharded import BinShardedSolver, disable_bin_sharding, enable_bin_sharding, shard_bounds  # noqa: F401
+
+__all__ = ["overiva", "auxiva_pca", "Plan", "BinShardedSolver", "enable_bin_sharding", "disable_bin_sharding",
+           "shard_bounds", "set_device", "get_device", "HipError", "HipLibraryMissing"]

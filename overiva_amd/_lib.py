@@ -1,0 +1,107 @@
+"""ctypes binding of liboveriva_hip.so (C ABI declared in include/overiva_hip.h).
+
+There is no fallback: if the shared library is missing or cannot be loaded the import of the
+product path fails with an explicit error.  ``python -m overiva_amd.build`` (or
+``__graft_entry__.build()``) produces the library.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "liboveriva_hip.so")
+
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NUMERIC = 0, -1, -2, -3, -4
+MODEL_IDS = {"laplace": 0, "gauss": 1}
+N_STAGES = 5
+STAGE_NAMES = ("demix_power", "r_sum", "r_finalize", "weighted_cov", "ip_update")
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+class HipError(RuntimeError):
+    """a HIP runtime call failed inside the library"""
+
+
+_lib = None
+
+_vp, _i, _ll, _fp = C.c_void_p, C.c_int, C.c_longlong, C.POINTER(C.c_float)
+
+# name -> argtypes ; every function returns int (see include/overiva_hip.h)
+SIGNATURES = {
+    "oiva_device_count": [C.POINTER(_i)],
+    "oiva_plan_create": [C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _vp],
+    "oiva_plan_destroy": [_vp],
+    "oiva_plan_set_x_host": [_vp, _vp, _ll],
+    "oiva_plan_set_x_dev": [_vp, _vp],
+    "oiva_plan_covariance": [_vp],
+    "oiva_plan_get_cx": [_vp, _vp],
+    "oiva_plan_set_w": [_vp, _vp],
+    "oiva_plan_iterate": [_vp, _i],
+    "oiva_plan_power": [_vp],
+    "oiva_plan_power_buffer": [_vp, C.POINTER(_vp), C.POINTER(_ll)],
+    "oiva_plan_update": [_vp, _vp, _i],
+    "oiva_plan_demix": [_vp, _vp, _ll, _i],
+    "oiva_plan_get_w": [_vp, _vp],
+    "oiva_plan_sync": [_vp],
+    "oiva_plan_iterate_timed": [_vp, _i, _fp, _fp],
+    "oiva_plan_get_cov_splits": [_vp, C.POINTER(_i)],
+    "oiva_plan_set_cov_splits": [_vp, _i],
+    "oiva_plan_use_graph": [_vp, _i],
+    "oiva_plan_set_precision": [_vp, _i],
+    "oiva_test_set_rinv": [_vp, _vp],
+    "oiva_test_get_rinv": [_vp, _vp, _vp],
+    "oiva_test_run_weighted_cov": [_vp],
+    "oiva_test_get_v": [_vp, _vp],
+    "oiva_test_run_update": [_vp],
+    "oiva_test_get_what": [_vp, _vp],
+    "oiva_test_set_what": [_vp, _vp],
+    "oiva_test_run_power": [_vp, _vp],
+}
+
+
+def load():
+    """Load the library once; raise HipLibraryMissing if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: the HIP extension is not built.  Run `python -m overiva_amd.build` "
+            "(needs hipcc).  overiva_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryMissing(f"cannot load {LIB_PATH}: {e}") from e
+    lib.oiva_version.restype = C.c_int
+    lib.oiva_version.argtypes = []
+    lib.oiva_last_error.restype = C.c_char_p
+    lib.oiva_last_error.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = load().oiva_last_error().decode("utf-8", "replace")
+    if rc == ERR_ARG:
+        raise ValueError(msg)
+    if rc == ERR_NUMERIC:
+        raise np.linalg.LinAlgError(msg)
+    if rc == ERR_STATE:
+        raise RuntimeError(msg)
+    raise HipError(msg)
+
+
+def ptr(a):
+    """raw pointer of a C-contiguous numpy array"""
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,341 @@
+// Kernels that apply the demixing vectors to X: the per-iteration source-power pass and the epilogue.
+//
+//   power : p[t,k] = sum_f |w_{f,k}^H x_{t,f}|^2      reference overiva.py:140 + the norms of :153/:155
+//           (Y itself is never stored inside the loop: the reference's Y /= gamma at :162/:166 is dead)
+//   stats : per-bin sums for projection back          reference overiva.py:197-198 (pyroomacoustics formula)
+//   write : Y[t,f,k] = w_{f,k}^H x_{t,f} (* conj z)   reference overiva.py:192-199
+#include "oiva_internal.h"
+
+namespace oiva {
+namespace {
+
+template <int M>
+__device__ __forceinline__ void load_x(const float2* __restrict__ p, float (&xr)[M], float (&xi)[M]) {
+    if constexpr (M % 2 == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+        for (int i = 0; i < M / 2; ++i) {
+            const float4 v = p4[i];
+            xr[2 * i] = v.x;
+            xi[2 * i] = v.y;
+            xr[2 * i + 1] = v.z;
+            xi[2 * i + 1] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const float2 v = p[i];
+            xr[i] = v.x;
+            xi[i] = v.y;
+        }
+    }
+}
+
+// conj(W[f][m][k0+kk]) for the lane's bin; W_hat is (F, M, M) row-major, column k = demixing vector k
+template <int M, int KP>
+__device__ __forceinline__ void load_wconj(const float2* __restrict__ What, int f, int k0, int K, float (&wr)[KP][M],
+                                           float (&wi)[KP][M]) {
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float2 v = make_float2(0.f, 0.f);
+            if (k0 + kk < K) v = What[((size_t)f * M + m) * M + k0 + kk];
+            wr[kk][m] = v.x;
+            wi[kk][m] = -v.y;
+        }
+    }
+}
+
+// y = sum_m conj(w_m) x_m
+template <int M>
+__device__ __forceinline__ void demix_one(const float (&wr)[M], const float (&wi)[M], const float (&xr)[M],
+                                          const float (&xi)[M], float& yr, float& yi) {
+    float ar = 0.f, ai = 0.f;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        ar = fmaf(wr[m], xr[m], ar);
+        ar = fmaf(-wi[m], xi[m], ar);
+        ai = fmaf(wr[m], xi[m], ai);
+        ai = fmaf(wi[m], xr[m], ai);
+    }
+    yr = ar;
+    yi = ai;
+}
+
+__device__ __forceinline__ float dpp_add(float v, const int ctrl_tag);
+
+// sum over the 16 lanes of a DPP row (= the 16 bins of one frame phase); every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    int x;
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141 /* row_half_mirror */, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140 /* row_mirror */, 0xF, 0xF, false);
+    v += __int_as_float(x);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// power: block = 4 waves x 16 bins = 64 bins, 4 frame phases per wave, frames [t_begin, t_begin+tcp)
+// ---------------------------------------------------------------------------------------------
+template <int M, int KP>
+__global__ __launch_bounds__(kBlock) void power_kernel(const float2* __restrict__ X, const float2* __restrict__ What,
+                                                       float* __restrict__ Ppart, int T, int F, int K, int tcp) {
+    extern __shared__ __attribute__((aligned(16))) float sp[];  // [kWaves][tcp][KP]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = lane & 15;
+    const int q = lane >> 4;
+    const int f = (blockIdx.x * kWaves + wave) * kBinsPerWave + b;
+    const bool fvalid = f < F;
+    const int fc = fvalid ? f : F - 1;
+    const int k0 = blockIdx.z * KP;
+    const int t_begin = blockIdx.y * tcp;
+    const int t_end = min(T, t_begin + tcp);
+    const int len = t_end - t_begin;
+    const int nsteps = (len + 3) >> 2;
+
+    float wr[KP][M], wi[KP][M];
+    load_wconj<M, KP>(What, fc, k0, K, wr, wi);
+
+    const size_t frame_stride = (size_t)F * M;
+    const float2* px = X + ((size_t)(t_begin + q) * F + fc) * M;
+    const float2* plast = X + ((size_t)(T - 1) * F + fc) * M;
+    for (int i = 0; i < nsteps; ++i) {
+        const int tl = 4 * i + q;
+        const bool live = tl < len;
+        float xr[M], xi[M];
+        load_x<M>(live ? px : plast, xr, xi);
+#pragma unroll
+        for (int kk = 0; kk < KP; ++kk) {
+            float yr, yi;
+            demix_one<M>(wr[kk], wi[kk], xr, xi, yr, yi);
+            float pw = fmaf(yr, yr, yi * yi);
+            pw = fvalid ? pw : 0.f;
+            pw = row16_sum(pw);
+            if (b == 0 && live) sp[(wave * tcp + tl) * KP + kk] = pw;
+        }
+        px += 4 * frame_stride;
+    }
+    __syncthreads();
+    for (int e = tid; e < len * KP; e += kBlock) {
+        const int tl = e / KP, kk = e - tl * KP;
+        float s = sp[(0 * tcp + tl) * KP + kk];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) s += sp[(w * tcp + tl) * KP + kk];
+        if (k0 + kk < K) Ppart[((size_t)blockIdx.x * T + t_begin + tl) * K + k0 + kk] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stats: same lane geometry as the covariance pass (16 bins per block, 16 frame phases);
+//        per (bin, source): num = sum_t conj(x_0) y,  den = sum_t |y|^2
+// ---------------------------------------------------------------------------------------------
+template <int M, int KP>
+__global__ __launch_bounds__(kBlock) void stats_kernel(const float2* __restrict__ X, const float2* __restrict__ What,
+                                                       float* __restrict__ Spart, int T, int F, int K, int tc) {
+    __shared__ float lds[3 * KP * (kBlock + 1)];
+    const int tid = threadIdx.x;
+    const int b = tid & 15;
+    const int q = tid >> 4;
+    const int f = blockIdx.x * kBinsPerWave + b;
+    const int fc = f < F ? f : F - 1;
+    const int k0 = blockIdx.z * KP;
+    const int t_begin = blockIdx.y * tc;
+    const int t_end = min(T, t_begin + tc);
+    const int nsteps = (t_end - t_begin + 15) >> 4;
+
+    float wr[KP][M], wi[KP][M];
+    load_wconj<M, KP>(What, fc, k0, K, wr, wi);
+    float nr[KP], ni[KP], dn[KP];
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) nr[kk] = ni[kk] = dn[kk] = 0.f;
+
+    const size_t frame_stride = (size_t)F * M;
+    const float2* px = X + ((size_t)(t_begin + q) * F + fc) * M;
+    for (int i = 0; i < nsteps; ++i) {
+        const int t = t_begin + q + 16 * i;
+        if (t < t_end) {
+            float xr[M], xi[M];
+            load_x<M>(px, xr, xi);
+#pragma unroll
+            for (int kk = 0; kk < KP; ++kk) {
+                float yr, yi;
+                demix_one<M>(wr[kk], wi[kk], xr, xi, yr, yi);
+                // conj(x0) * y
+                nr[kk] = fmaf(xr[0], yr, fmaf(xi[0], yi, nr[kk]));
+                ni[kk] = fmaf(xr[0], yi, fmaf(-xi[0], yr, ni[kk]));
+                dn[kk] = fmaf(yr, yr, fmaf(yi, yi, dn[kk]));
+            }
+        }
+        px += 16 * frame_stride;
+    }
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+        lds[(3 * kk + 0) * (kBlock + 1) + tid] = nr[kk];
+        lds[(3 * kk + 1) * (kBlock + 1) + tid] = ni[kk];
+        lds[(3 * kk + 2) * (kBlock + 1) + tid] = dn[kk];
+    }
+    __syncthreads();
+    // thread e -> (bin bb, value v): sum the 16 phases
+    for (int e = tid; e < 16 * 3 * KP; e += kBlock) {
+        const int bb = e / (3 * KP), v = e - bb * (3 * KP);
+        float s = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) s += lds[v * (kBlock + 1) + qq * 16 + bb];
+        const int fo = blockIdx.x * kBinsPerWave + bb;
+        const int kk = v / 3, c = v - 3 * kk;
+        if (fo < F && k0 + kk < K) Spart[(((size_t)blockIdx.y * F + fo) * K + k0 + kk) * 3 + c] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// write: Y (T, F, K) complex64; z from the stats partials when projecting back
+// ---------------------------------------------------------------------------------------------
+template <int M, int KP>
+__global__ __launch_bounds__(kBlock) void write_kernel(const float2* __restrict__ X, const float2* __restrict__ What,
+                                                       const float* __restrict__ Spart, int nsplit,
+                                                       float2* __restrict__ Y, int T, int F, int K, int tc) {
+    const int tid = threadIdx.x;
+    const int b = tid & 15;
+    const int q = tid >> 4;
+    const int f = blockIdx.x * kBinsPerWave + b;
+    if (f >= F) return;
+    const int k0 = blockIdx.z * KP;
+    const int t_begin = blockIdx.y * tc;
+    const int t_end = min(T, t_begin + tc);
+
+    float wr[KP][M], wi[KP][M];
+    load_wconj<M, KP>(What, f, k0, K, wr, wi);
+    // fold conj(z) into the demixing vector: y*conj(z) = (conj(z) w^H) x
+    if (Spart != nullptr) {
+#pragma unroll
+        for (int kk = 0; kk < KP; ++kk) {
+            if (k0 + kk < K) {
+                double sr = 0., si = 0., sd = 0.;
+                for (int s = 0; s < nsplit; ++s) {
+                    const float* p = Spart + (((size_t)s * F + f) * K + k0 + kk) * 3;
+                    sr += p[0];
+                    si += p[1];
+                    sd += p[2];
+                }
+                float zr = 1.f, zi = 0.f;
+                if (sd > 0.) {
+                    zr = (float)(sr / sd);
+                    zi = (float)(si / sd);
+                }
+                // multiply conj(w) (held as wr + i wi) by conj(z) = zr - i zi
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const float a = wr[kk][m], c = wi[kk][m];
+                    wr[kk][m] = a * zr + c * zi;
+                    wi[kk][m] = c * zr - a * zi;
+                }
+            }
+        }
+    }
+    const size_t frame_stride = (size_t)F * M;
+    const float2* px = X + ((size_t)(t_begin + q) * F + f) * M;
+    for (int t = t_begin + q; t < t_end; t += 16) {
+        float xr[M], xi[M];
+        load_x<M>(px, xr, xi);
+#pragma unroll
+        for (int kk = 0; kk < KP; ++kk) {
+            float yr, yi;
+            demix_one<M>(wr[kk], wi[kk], xr, xi, yr, yi);
+            if (k0 + kk < K) Y[((size_t)t * F + f) * K + k0 + kk] = make_float2(yr, yi);
+        }
+        px += 16 * frame_stride;
+    }
+}
+
+template <int M, int KP>
+hipError_t launch_power_one(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int K,
+                            const PowGeom& g) {
+    dim3 grid(g.nb, g.nsplit, (K + KP - 1) / KP);
+    const size_t shmem = (size_t)kWaves * g.tcp * KP * sizeof(float);
+    hipLaunchKernelGGL((power_kernel<M, KP>), grid, dim3(kBlock), shmem, s, X, What, Ppart, T, F, K, g.tcp);
+    return hipGetLastError();
+}
+
+template <int M, int KP>
+hipError_t launch_stats_one(hipStream_t s, const float2* X, const float2* What, float* Spart, int T, int F, int K,
+                            const CovGeom& g) {
+    dim3 grid(g.nbg, g.nsplit, (K + KP - 1) / KP);
+    hipLaunchKernelGGL((stats_kernel<M, KP>), grid, dim3(kBlock), 0, s, X, What, Spart, T, F, K, g.tc);
+    return hipGetLastError();
+}
+
+template <int M, int KP>
+hipError_t launch_write_one(hipStream_t s, const float2* X, const float2* What, const float* Spart, int nsplit,
+                            float2* Y, int T, int F, int K) {
+    const int tc = 256;
+    dim3 grid((F + kBinsPerWave - 1) / kBinsPerWave, (T + tc - 1) / tc, (K + KP - 1) / KP);
+    hipLaunchKernelGGL((write_kernel<M, KP>), grid, dim3(kBlock), 0, s, X, What, Spart, nsplit, Y, T, F, K, tc);
+    return hipGetLastError();
+}
+
+// dispatch (M, KP) -> instantiation.  KP in {1, 2, 4}.
+#define OIVA_DISPATCH_M(CALL)            \
+    switch (M) {                         \
+        case 1: CALL(1); break;          \
+        case 2: CALL(2); break;          \
+        case 3: CALL(3); break;          \
+        case 4: CALL(4); break;          \
+        case 5: CALL(5); break;          \
+        case 6: CALL(6); break;          \
+        case 7: CALL(7); break;          \
+        case 8: CALL(8); break;          \
+        case 9: CALL(9); break;          \
+        case 10: CALL(10); break;        \
+        case 11: CALL(11); break;        \
+        case 12: CALL(12); break;        \
+        case 13: CALL(13); break;        \
+        case 14: CALL(14); break;        \
+        case 15: CALL(15); break;        \
+        case 16: CALL(16); break;        \
+    }
+
+}  // namespace
+
+int pow_sources_per_pass(int M, int K) {
+    if (K >= 3 && M <= 8) return 4;
+    if (K >= 2) return 2;
+    return 1;
+}
+
+hipError_t launch_power(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K,
+                        const PowGeom& g) {
+#define CALL(MM)                                                                                        \
+    if (g.kp == 1) return launch_power_one<MM, 1>(s, X, What, Ppart, T, F, K, g);                       \
+    if (g.kp == 2) return launch_power_one<MM, 2>(s, X, What, Ppart, T, F, K, g);                       \
+    if constexpr (MM <= 8) {                                                                            \
+        if (g.kp == 4) return launch_power_one<MM, 4>(s, X, What, Ppart, T, F, K, g);                   \
+    }
+    OIVA_DISPATCH_M(CALL)
+#undef CALL
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_demix_stats(hipStream_t s, const float2* X, const float2* What, float* Spart, int T, int F, int M,
+                              int K, const CovGeom& g) {
+#define CALL(MM) return launch_stats_one<MM, 2>(s, X, What, Spart, T, F, K, g);
+    OIVA_DISPATCH_M(CALL)
+#undef CALL
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_demix_write(hipStream_t s, const float2* X, const float2* What, const float* Spart, int nsplit,
+                              float2* Y, int T, int F, int M, int K) {
+#define CALL(MM) return launch_write_one<MM, 2>(s, X, What, Spart, nsplit, Y, T, F, K);
+    OIVA_DISPATCH_M(CALL)
+#undef CALL
+    return hipErrorInvalidValue;
+}
+
+}  // namespace oiva

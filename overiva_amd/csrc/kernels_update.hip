@@ -1,0 +1,319 @@
+// Per-bin sequential algebra of one iteration                       reference overiva.py:176-190
+//
+//   for s in 0..K-1:
+//       V_s   = (1/T) * sum of the covariance partials                       (:179, reduction tail)
+//       A     = W_hat^H V_s ;  w_s = A^{-1} e_s                              (:181-182, IP1)
+//       w_s  /= sqrt(w_s^H V_s w_s)                                          (:185-186)
+//       J     = (W^H Cx)[:, :K]^{-1} (W^H Cx)[:, K:]   when K < M            (:189-190 -> :96-98)
+//   plus, on entry, the pending scale normalisation W[:, k] /= wscale[k]     (:163 / :167)
+//   and, with init_only, just the J initialisation of the prologue           (:120-123)
+//
+// One bin is handled by a group of SG lanes (SG = next power of two >= M); lane i holds ROW i of the
+// matrices: row i of W_hat^H (i.e. conj of column i of W_hat), of Cx, of V_s, of A.  Rows are
+// exchanged with sub-group shuffles; Gauss-Jordan elimination with partial pivoting never moves a
+// row (the pivot lane just broadcasts).  Every register array is indexed with compile-time
+// constants only (loops over columns are fully unrolled; run-time M and K enter as predicates).
+#include "oiva_internal.h"
+
+namespace oiva {
+namespace {
+
+template <typename R>
+struct Cx {
+    R re, im;
+};
+template <typename R>
+__device__ __forceinline__ Cx<R> cmul(Cx<R> a, Cx<R> b) {
+    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+template <typename R>
+__device__ __forceinline__ void cfma(Cx<R>& acc, Cx<R> a, Cx<R> b) {  // acc += a*b
+    acc.re += a.re * b.re - a.im * b.im;
+    acc.im += a.re * b.im + a.im * b.re;
+}
+template <typename R>
+__device__ __forceinline__ void cfms(Cx<R>& acc, Cx<R> a, Cx<R> b) {  // acc -= a*b
+    acc.re -= a.re * b.re - a.im * b.im;
+    acc.im -= a.re * b.im + a.im * b.re;
+}
+template <typename R>
+__device__ __forceinline__ Cx<R> cinv(Cx<R> a) {
+    const R d = a.re * a.re + a.im * a.im;
+    return {a.re / d, -a.im / d};
+}
+template <int SG, typename R>
+__device__ __forceinline__ R gshfl(R v, int src) {
+    return __shfl(v, src, SG);
+}
+template <int SG, typename R>
+__device__ __forceinline__ Cx<R> gshfl(Cx<R> v, int src) {
+    return {__shfl(v.re, src, SG), __shfl(v.im, src, SG)};
+}
+template <int SG, typename R>
+__device__ __forceinline__ R gsum(R v) {
+#pragma unroll
+    for (int off = SG / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, SG);
+    return v;
+}
+
+// Gauss-Jordan elimination on rows held one per lane.  Pivots columns 0..npiv-1 (npiv uniform);
+// rows with used == true are never chosen.  On return: perm[c] = lane that pivoted column c,
+// piv = the pivot element of this lane's own row (if it pivoted), every non-pivot row has a zero in
+// each pivoted column, rhs transformed alongside.
+template <int SG, typename R>
+__device__ __forceinline__ void gauss_jordan(Cx<R> (&A)[SG], Cx<R>& rhs, int npiv, bool used, int (&perm)[SG],
+                                             Cx<R>& piv, int i) {
+#pragma unroll
+    for (int c = 0; c < SG; ++c) {
+        perm[c] = c;
+        if (c < npiv) {
+            R mag = used ? R(-1) : (A[c].re * A[c].re + A[c].im * A[c].im);
+            int bl = i;
+#pragma unroll
+            for (int off = SG / 2; off > 0; off >>= 1) {
+                const R om = __shfl_xor(mag, off, SG);
+                const int ol = __shfl_xor(bl, off, SG);
+                const bool take = (om > mag) || (om == mag && ol < bl);
+                mag = take ? om : mag;
+                bl = take ? ol : bl;
+            }
+            const int p = bl;
+            perm[c] = p;
+            const bool isp = (i == p);
+            const Cx<R> pc = gshfl<SG>(A[c], p);
+            const Cx<R> fct = cmul(A[c], cinv(pc));
+            if (isp) {
+                used = true;
+                piv = A[c];
+            }
+            const Cx<R> pb = gshfl<SG>(rhs, p);
+            if (!isp) cfms(rhs, fct, pb);
+#pragma unroll
+            for (int j = c + 1; j < SG; ++j) {
+                const Cx<R> pj = gshfl<SG>(A[j], p);
+                if (!isp) cfms(A[j], fct, pj);
+            }
+            if (!isp) A[c] = {R(0), R(0)};
+        }
+    }
+}
+
+// entry (i, j) of a packed Hermitian matrix (see herm_pair_index), as a complex number
+__device__ __forceinline__ void herm_offsets(int M, int i, int j, int& off, float& sgn) {
+    if (i == j) {
+        off = i;
+        sgn = 0.f;  // no imaginary part
+    } else if (i < j) {
+        off = herm_pair_index(M, i, j);
+        sgn = 1.f;
+    } else {
+        off = herm_pair_index(M, j, i);
+        sgn = -1.f;
+    }
+}
+
+template <int SG, typename R>
+__global__ __launch_bounds__(kBlock) void update_kernel(UpdateArgs a) {
+    const int tid = threadIdx.x;
+    const int i = tid % SG;
+    const int grp = tid / SG;
+    const int f_raw = blockIdx.x * (kBlock / SG) + grp;
+    const bool fvalid = f_raw < a.F;
+    const int f = fvalid ? f_raw : a.F - 1;
+    const int M = a.M, K = a.K;
+    const int NA = M * M;
+    const bool row_ok = i < M;
+    const Cx<R> zero = {R(0), R(0)};
+
+    // B = row i of W_hat^H: B[m] = conj(W_hat[f][m][i]); padded rows/cols are identity
+    Cx<R> B[SG], C[SG], Tm[SG];
+#pragma unroll
+    for (int m = 0; m < SG; ++m) {
+        B[m] = {R(m == i ? 1 : 0), R(0)};
+        if (m < M && row_ok) {
+            const float2 v = a.What[((size_t)f * M + m) * M + i];
+            B[m] = {R(v.x), R(-v.y)};
+        }
+    }
+    if (a.wscale != nullptr && i < K) {  // overiva.py:163 / :167
+        const R s = R(1) / R(a.wscale[i]);
+#pragma unroll
+        for (int m = 0; m < SG; ++m) {
+            B[m].re *= s;
+            B[m].im *= s;
+        }
+    }
+    // C = row i of Cx
+#pragma unroll
+    for (int j = 0; j < SG; ++j) {
+        C[j] = zero;
+        if (j < M && row_ok) {
+            int off;
+            float sgn;
+            herm_offsets(M, i, j, off, sgn);
+            const float* p = a.Cx + (size_t)f * NA + off;
+            C[j].re = R(p[0]);
+            if (sgn != 0.f) C[j].im = R(sgn * p[1]);
+        }
+    }
+    // Tm = row i of W^H Cx for i < K (kept across the source loop; only row s changes per source)
+#pragma unroll
+    for (int j = 0; j < SG; ++j) Tm[j] = zero;
+    if (K < M) {
+#pragma unroll
+        for (int m = 0; m < SG; ++m) {
+            if (m < M) {
+#pragma unroll
+                for (int j = 0; j < SG; ++j) {
+                    const Cx<R> cj = gshfl<SG>(C[j], m);
+                    cfma(Tm[j], B[m], cj);
+                }
+            }
+        }
+    }
+
+    const int nsrc = a.init_only ? 0 : K;
+    const R invT = R(1) / R(a.T);
+    for (int s = 0; s <= nsrc; ++s) {
+        const bool solve = s < nsrc;       // the last trip (s == nsrc) exists only for init_only's J update
+        if (!solve && !a.init_only) break;
+        Cx<R> w[SG];
+        Cx<R> own = zero;
+        if (solve) {
+            // V row i: fixed-order fp64 sum of the frame-split partials
+            Cx<R> Vr[SG];
+#pragma unroll
+            for (int j = 0; j < SG; ++j) {
+                Vr[j] = zero;
+                if (j < M && row_ok) {
+                    int off;
+                    float sgn;
+                    herm_offsets(M, i, j, off, sgn);
+                    double sr = 0., si = 0.;
+                    for (int sp = 0; sp < a.nsplit; ++sp) {
+                        const float* p = a.Vpart + (((size_t)sp * a.F + f) * K + s) * NA + off;
+                        sr += (double)p[0];
+                        if (sgn != 0.f) si += (double)p[1];
+                    }
+                    Vr[j].re = R(sr) * invT;
+                    Vr[j].im = R(si) * R(sgn) * invT;
+                }
+            }
+            // A = W_hat^H V
+            Cx<R> A[SG];
+#pragma unroll
+            for (int j = 0; j < SG; ++j) A[j] = zero;
+#pragma unroll
+            for (int m = 0; m < SG; ++m) {
+                if (m < M) {
+#pragma unroll
+                    for (int j = 0; j < SG; ++j) {
+                        const Cx<R> vj = gshfl<SG>(Vr[j], m);
+                        cfma(A[j], B[m], vj);
+                    }
+                }
+            }
+            if (!row_ok) {
+#pragma unroll
+                for (int j = 0; j < SG; ++j) A[j] = {R(j == i ? 1 : 0), R(0)};
+            }
+            Cx<R> rhs = {R(i == s ? 1 : 0), R(0)};
+            int perm[SG];
+            Cx<R> piv = {R(1), R(0)};
+            gauss_jordan<SG, R>(A, rhs, SG, false, perm, piv, i);
+            // w[c] lives on lane perm[c] as rhs / pivot; gather the whole vector on every lane
+            const Cx<R> q = cmul(rhs, cinv(piv));
+#pragma unroll
+            for (int c = 0; c < SG; ++c) {
+                w[c] = gshfl<SG>(q, perm[c]);
+                if (c == i) own = w[c];
+            }
+            // normalise by sqrt(w^H V w) (real and positive for Hermitian PSD V)
+            Cx<R> u = zero;
+#pragma unroll
+            for (int j = 0; j < SG; ++j) cfma(u, Vr[j], w[j]);
+            const R d = gsum<SG, R>(own.re * u.re + own.im * u.im);
+            const R sc = R(1) / sqrt(d);
+#pragma unroll
+            for (int c = 0; c < SG; ++c) {
+                w[c].re *= sc;
+                w[c].im *= sc;
+            }
+            own.re *= sc;
+            own.im *= sc;
+            if (i == s) {
+#pragma unroll
+                for (int m = 0; m < SG; ++m) B[m] = {w[m].re, -w[m].im};
+            }
+        }
+        if (K < M) {
+            if (solve) {
+                // row s of W^H Cx: sum over lanes m of conj(w_m) * Cx[m][:]
+                Cx<R> t[SG];
+                const Cx<R> oc = {own.re, -own.im};
+#pragma unroll
+                for (int j = 0; j < SG; ++j) {
+                    t[j] = cmul(oc, C[j]);
+                    t[j].re = gsum<SG, R>(t[j].re);
+                    t[j].im = gsum<SG, R>(t[j].im);
+                }
+                if (i == s) {
+#pragma unroll
+                    for (int j = 0; j < SG; ++j) Tm[j] = t[j];
+                }
+            }
+            // J: eliminate columns 0..K-1 among rows 0..K-1 of [Tm]; J[c][j-K] = G[j]/pivot on lane perm[c]
+            Cx<R> G[SG];
+#pragma unroll
+            for (int j = 0; j < SG; ++j) G[j] = (i < K) ? Tm[j] : Cx<R>{R(j == i ? 1 : 0), R(0)};
+            Cx<R> dummy = zero;
+            int perm[SG];
+            Cx<R> piv = {R(1), R(0)};
+            gauss_jordan<SG, R>(G, dummy, K, i >= K, perm, piv, i);
+            const Cx<R> ip = cinv(piv);
+#pragma unroll
+            for (int m = 0; m < SG; ++m) {
+                if (m < K) {
+#pragma unroll
+                    for (int j = 0; j < SG; ++j) {
+                        if (j >= K && j < M) {
+                            const Cx<R> val = gshfl<SG>(cmul(G[j], ip), perm[m]);
+                            // W_hat[m][j] = J[m][j-K]  ->  row j of W_hat^H, entry m = conj
+                            if (i == j) B[m] = {val.re, -val.im};
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (fvalid && row_ok) {
+#pragma unroll
+        for (int m = 0; m < SG; ++m) {
+            if (m < M) a.What[((size_t)f * M + m) * M + i] = make_float2((float)B[m].re, (float)(-B[m].im));
+        }
+    }
+}
+
+template <int SG>
+hipError_t launch_sg(hipStream_t s, const UpdateArgs& a) {
+    const int bins_per_block = kBlock / SG;
+    dim3 grid((a.F + bins_per_block - 1) / bins_per_block);
+    if (a.use_double)
+        hipLaunchKernelGGL((update_kernel<SG, double>), grid, dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL((update_kernel<SG, float>), grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_update(hipStream_t s, const UpdateArgs& a) {
+    if (a.M <= 2) return launch_sg<2>(s, a);
+    if (a.M <= 4) return launch_sg<4>(s, a);
+    if (a.M <= 8) return launch_sg<8>(s, a);
+    if (a.M <= 16) return launch_sg<16>(s, a);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace oiva

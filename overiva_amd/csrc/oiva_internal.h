@@ -1,0 +1,89 @@
+// Internal declarations shared by the translation units of liboveriva_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "overiva_hip.h"
+
+namespace oiva {
+
+// ---- lane geometry shared by the streaming kernels -------------------------------------------
+// A wave is 16 bins x 4 frame phases: lane l -> bin (l & 15), phase (l >> 4).  The 16 bins of one
+// frame are 16*M*8 contiguous bytes of the native (T, F, M) complex64 tensor, so one wave touches
+// four contiguous runs per step and every byte of every cache line it opens is consumed.
+constexpr int kBinsPerWave = 16;
+constexpr int kPhasesPerWave = 4;
+constexpr int kBlock = 256;  // 4 waves
+constexpr int kWaves = kBlock / 64;
+
+// packed Hermitian layout of one M x M covariance: M real diagonals, then for every c < d
+// (row-major) the pair (re, im) of V[c][d] = sum w * x_c * conj(x_d).  M*M floats in total.
+__host__ __device__ inline int herm_pair_index(int M, int c, int d) {  // c < d
+    return M + 2 * (c * M - (c * (c + 1)) / 2 + (d - c - 1));
+}
+
+struct CovGeom {
+    int nsplit;   // frame splits (grid.y)
+    int tc;       // frames per split (multiple of 16)
+    int kc;       // sources per pass (template KC)
+    int nbg;      // bin groups of 16 (grid.x)
+};
+struct PowGeom {
+    int nb;       // bin batches of 64 (grid.x)
+    int nsplit;   // frame splits (grid.y)
+    int tcp;      // frames per split (multiple of 4, <= kPowMaxFrames)
+    int kp;       // sources per pass
+};
+constexpr int kPowMaxFrames = 512;
+
+// ---- launchers (one per kernel family; each .hip file owns its template instantiations) -------
+// Weighted covariance pass, overiva.py:179 (and :87 with unit weights).
+//   X (T,F,M) c64, rinv (T,K) f32 or nullptr for unit weights (then K must be 1)
+//   Vpart [nsplit][F][K][M*M] packed partial sums (NOT divided by T)
+hipError_t launch_cov(hipStream_t s, const float2* X, const float* rinv, float* Vpart, int T, int F, int M,
+                      int K, const CovGeom& g);
+int cov_sources_per_pass(int M, int K);
+bool cov_supported(int M);
+
+// Demix + source power, overiva.py:140 + the norms at :153/:155.
+//   What (F,M,M) c64 row-major;  Ppart [nb][T][K]
+hipError_t launch_power(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M,
+                        int K, const PowGeom& g);
+int pow_sources_per_pass(int M, int K);
+
+// Activation finalisation, overiva.py:152-173.
+//   parts [nparts][T][K] -> R (T,K) unnormalised r, Gsum [nblk][K] per-block sums of r
+hipError_t launch_rsum(hipStream_t s, const float* parts, int nparts, float* R, double* Gsum, int T, int K, int model,
+                       int F_total);
+//   R, Gsum -> Rinv (T,K) = 1/max(r/gamma, 1e-15), wscale (K) = gamma | sqrt(gamma)
+hipError_t launch_rfin(hipStream_t s, const float* R, const double* Gsum, float* Rinv, float* wscale, int T, int K,
+                       int model);
+int rsum_blocks(int T);
+// sum of partial buffers: out[e] = sum_i parts[i][e]
+hipError_t launch_sum_parts(hipStream_t s, const float* parts, int nparts, float* out, long long n, float scale);
+
+// Per-bin sequential update, overiva.py:181-190 (+ :161-167 W scaling, + :96-98 J init when init_only).
+struct UpdateArgs {
+    float2* What;         // (F,M,M) in/out
+    const float* Cx;      // [F][M*M] packed, already divided by T
+    const float* Vpart;   // [nsplit][F][K][M*M] packed partial sums
+    const float* wscale;  // (K) or nullptr
+    int nsplit;
+    int T, F, M, K;
+    int init_only;        // 1: only (re)compute J from W and Cx
+    int use_double;       // per-bin algebra in fp64
+};
+hipError_t launch_update(hipStream_t s, const UpdateArgs& a);
+
+// Epilogue, overiva.py:192-199.
+//   stats: per-bin sums for projection back: [nsplit][F][K][3] = (Re num, Im num, den)
+hipError_t launch_demix_stats(hipStream_t s, const float2* X, const float2* What, float* Spart, int T, int F, int M,
+                              int K, const CovGeom& g);
+//   write Y (T,F,K) c64, scaled by conj(z) when Spart != nullptr
+hipError_t launch_demix_write(hipStream_t s, const float2* X, const float2* What, const float* Spart, int nsplit,
+                              float2* Y, int T, int F, int M, int K);
+// unpack packed Hermitian [F][K?][M*M] -> full complex (F,M,M) with scale
+hipError_t launch_unpack_herm(hipStream_t s, const float* packed, float2* full, long long nmat, int M, float scale);
+
+}  // namespace oiva

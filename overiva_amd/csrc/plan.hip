@@ -1,0 +1,642 @@
+// C ABI of liboveriva_hip.so (see include/overiva_hip.h): plan life cycle, prologue, iteration,
+// epilogue, measurement and test-only stage access.  Host code only; kernels live in kernels_*.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "oiva_internal.h"
+
+using namespace oiva;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(OIVA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define NEED(cond, code, msg) \
+    do {                      \
+        if (!(cond)) return fail(code, msg); \
+    } while (0)
+
+int round_up(int a, int b) { return (a + b - 1) / b * b; }
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+constexpr int kTargetBlocks = 768;  // ~3 workgroups of 4 waves per CU on 256 CUs
+
+}  // namespace
+
+struct oiva_plan {
+    int device = 0;
+    int T = 0, F = 0, M = 0, K = 0, model = 0, F_total = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    const float2* X = nullptr;  // (T,F,M)
+    float2* X_owned = nullptr;
+    float2* What = nullptr;     // (F,M,M)
+    float* Cx = nullptr;        // [F][M*M] packed, / T
+    float* Vpart = nullptr;     // [nsplit][F][K][M*M]
+    float* Ppart = nullptr;     // [nb][T][K]
+    float* Plocal = nullptr;    // (T,K)
+    float* R = nullptr;         // (T,K)
+    float* Rinv = nullptr;      // (T,K)
+    double* Gsum = nullptr;     // [rsum_blocks][K]
+    float* wscale = nullptr;    // (K)
+    float* Spart = nullptr;     // [nsplit][F][K][3]
+    float2* Y = nullptr;        // (T,F,K), allocated on first demix
+    float2* scratch_c = nullptr;  // max(F*M*M, K*F*M*M) complex, for getters
+
+    CovGeom cov{};
+    PowGeom pw{};
+    int vpart_splits_alloc = 0;
+
+    bool have_x = false, have_cx = false, have_w = false;
+    bool wscale_pending = false;  // Rinv / wscale computed, update not yet applied
+    int use_double = 0;
+    int use_graph = 0;
+    hipGraphExec_t graph_exec = nullptr;
+    hipEvent_t ev[2] = {};
+};
+
+namespace {
+
+void choose_cov_geom(oiva_plan* p, int nsplit_req) {
+    CovGeom g;
+    g.nbg = ceil_div(p->F, kBinsPerWave);
+    g.kc = cov_sources_per_pass(p->M, p->K);
+    int nsplit = nsplit_req > 0 ? nsplit_req : std::max(1, (kTargetBlocks + g.nbg - 1) / g.nbg);
+    // at least 32 frames per split (2 steps per lane), frames per split a multiple of 16
+    int tc = round_up(ceil_div(p->T, nsplit), 16);
+    if (nsplit_req <= 0) tc = std::max(tc, 32);
+    g.tc = tc;
+    g.nsplit = ceil_div(p->T, tc);
+    p->cov = g;
+}
+
+void choose_pow_geom(oiva_plan* p) {
+    PowGeom g;
+    g.nb = ceil_div(p->F, kBinsPerWave * kWaves);
+    g.kp = pow_sources_per_pass(p->M, p->K);
+    int nsplit = std::max(1, (kTargetBlocks + g.nb - 1) / g.nb);
+    int tcp = round_up(ceil_div(p->T, nsplit), 4);
+    tcp = std::max(tcp, 16);
+    tcp = std::min(tcp, kPowMaxFrames);
+    g.tcp = tcp;
+    g.nsplit = ceil_div(p->T, tcp);
+    p->pw = g;
+}
+
+int drop_graph(oiva_plan* p) {
+    if (p->graph_exec) {
+        HIP_TRY(hipGraphExecDestroy(p->graph_exec));
+        p->graph_exec = nullptr;
+    }
+    return OIVA_OK;
+}
+
+size_t vpart_floats(const oiva_plan* p, int nsplit) { return (size_t)nsplit * p->F * p->K * p->M * p->M; }
+
+int ensure_vpart(oiva_plan* p) {
+    if (p->cov.nsplit > p->vpart_splits_alloc) {
+        if (p->Vpart) HIP_TRY(hipFree(p->Vpart));
+        p->Vpart = nullptr;
+        if (p->Spart) HIP_TRY(hipFree(p->Spart));
+        p->Spart = nullptr;
+        HIP_TRY(hipMalloc(&p->Vpart, vpart_floats(p, p->cov.nsplit) * sizeof(float)));
+        HIP_TRY(hipMalloc(&p->Spart, (size_t)p->cov.nsplit * p->F * p->K * 3 * sizeof(float)));
+        p->vpart_splits_alloc = p->cov.nsplit;
+    }
+    return OIVA_OK;
+}
+
+// ---- the five stages of one iteration -----------------------------------------------------------
+int stage_power(oiva_plan* p) {
+    HIP_TRY(launch_power(p->stream, p->X, p->What, p->Ppart, p->T, p->F, p->M, p->K, p->pw));
+    return OIVA_OK;
+}
+int stage_rsum(oiva_plan* p, const float* parts, int nparts) {
+    HIP_TRY(launch_rsum(p->stream, parts, nparts, p->R, p->Gsum, p->T, p->K, p->model, p->F_total));
+    return OIVA_OK;
+}
+int stage_rfin(oiva_plan* p) {
+    HIP_TRY(launch_rfin(p->stream, p->R, p->Gsum, p->Rinv, p->wscale, p->T, p->K, p->model));
+    p->wscale_pending = true;
+    return OIVA_OK;
+}
+int stage_cov(oiva_plan* p) {
+    HIP_TRY(launch_cov(p->stream, p->X, p->Rinv, p->Vpart, p->T, p->F, p->M, p->K, p->cov));
+    return OIVA_OK;
+}
+int stage_update(oiva_plan* p, bool init_only) {
+    UpdateArgs a;
+    a.What = p->What;
+    a.Cx = p->Cx;
+    a.Vpart = p->Vpart;
+    a.wscale = (!init_only && p->wscale_pending) ? p->wscale : nullptr;
+    a.nsplit = p->cov.nsplit;
+    a.T = p->T;
+    a.F = p->F;
+    a.M = p->M;
+    a.K = p->K;
+    a.init_only = init_only ? 1 : 0;
+    a.use_double = p->use_double;
+    HIP_TRY(launch_update(p->stream, a));
+    if (!init_only) p->wscale_pending = false;
+    return OIVA_OK;
+}
+
+int one_iteration(oiva_plan* p) {
+    int rc;
+    if ((rc = stage_power(p))) return rc;
+    if ((rc = stage_rsum(p, p->Ppart, p->pw.nb))) return rc;
+    if ((rc = stage_rfin(p))) return rc;
+    if ((rc = stage_cov(p))) return rc;
+    return stage_update(p, false);
+}
+
+int check_ready(oiva_plan* p) {
+    NEED(p != nullptr, OIVA_ERR_ARG, "null plan");
+    NEED(p->have_x, OIVA_ERR_STATE, "X not set (oiva_plan_set_x_host/_dev)");
+    NEED(p->have_cx, OIVA_ERR_STATE, "input covariance not computed (oiva_plan_covariance)");
+    NEED(p->have_w, OIVA_ERR_STATE, "demixing matrix not set (oiva_plan_set_w)");
+    return OIVA_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (prev >= 0 && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int oiva_version(void) { return 100; }
+
+const char* oiva_last_error(void) { return g_err.c_str(); }
+
+int oiva_device_count(int* n) {
+    NEED(n != nullptr, OIVA_ERR_ARG, "null pointer");
+    HIP_TRY(hipGetDeviceCount(n));
+    return OIVA_OK;
+}
+
+int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, int model, int F_total, void* stream) {
+    NEED(out != nullptr, OIVA_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    NEED(T >= 1 && F >= 1, OIVA_ERR_ARG, "T and F must be >= 1");
+    NEED(M >= 1 && M <= OIVA_MAX_CHANNELS, OIVA_ERR_ARG, "number of channels must be in 1..16");
+    NEED(K >= 1 && K <= M, OIVA_ERR_ARG, "n_src must be in 1..n_chan");
+    NEED(model == OIVA_MODEL_LAPLACE || model == OIVA_MODEL_GAUSS, OIVA_ERR_ARG, "unknown model");
+    NEED(F_total >= F, OIVA_ERR_ARG, "F_total must be >= F");
+    NEED(cov_supported(M), OIVA_ERR_ARG, "this build supports up to 8 channels in the covariance pass");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    NEED(device >= 0 && device < ndev, OIVA_ERR_ARG, "no such device");
+    DeviceGuard guard(device);
+
+    oiva_plan* p = new oiva_plan();
+    p->device = device;
+    p->T = T;
+    p->F = F;
+    p->M = M;
+    p->K = K;
+    p->model = model;
+    p->F_total = F_total;
+    if (stream) {
+        p->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete p;
+            return fail(OIVA_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        }
+        p->own_stream = true;
+    }
+    choose_cov_geom(p, 0);
+    choose_pow_geom(p);
+    const size_t nTK = (size_t)T * K;
+    const size_t nFMM = (size_t)F * M * M;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** ptr, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(ptr, bytes);
+    };
+    alloc((void**)&p->What, nFMM * sizeof(float2));
+    alloc((void**)&p->Cx, nFMM * sizeof(float));
+    alloc((void**)&p->Ppart, (size_t)p->pw.nb * nTK * sizeof(float));
+    alloc((void**)&p->Plocal, nTK * sizeof(float));
+    alloc((void**)&p->R, nTK * sizeof(float));
+    alloc((void**)&p->Rinv, nTK * sizeof(float));
+    alloc((void**)&p->Gsum, (size_t)rsum_blocks(T) * K * sizeof(double));
+    alloc((void**)&p->wscale, (size_t)K * sizeof(float));
+    alloc((void**)&p->scratch_c, (size_t)std::max(1, K) * nFMM * sizeof(float2));
+    for (auto& ev : p->ev) {
+        if (e == hipSuccess) e = hipEventCreate(&ev);
+    }
+    if (e != hipSuccess) {
+        oiva_plan_destroy(p);
+        return fail(OIVA_ERR_HIP, std::string("allocation failed: ") + hipGetErrorString(e));
+    }
+    int rc = ensure_vpart(p);
+    if (rc) {
+        oiva_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return OIVA_OK;
+}
+
+int oiva_plan_destroy(oiva_plan* p) {
+    if (!p) return OIVA_OK;
+    DeviceGuard guard(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    void* bufs[] = {p->X_owned, p->What, p->Cx,     p->Vpart, p->Ppart, p->Plocal, p->R,
+                    p->Rinv,    p->Gsum, p->wscale, p->Spart, p->Y,     p->scratch_c};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    for (auto& ev : p->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return OIVA_OK;
+}
+
+int oiva_plan_set_x_host(oiva_plan* p, const void* X, long long row_pitch_bytes) {
+    NEED(p && X, OIVA_ERR_ARG, "null argument");
+    DeviceGuard guard(p->device);
+    const size_t row = (size_t)p->F * p->M * sizeof(float2);
+    const size_t pitch = row_pitch_bytes > 0 ? (size_t)row_pitch_bytes : row;
+    NEED(pitch >= row, OIVA_ERR_ARG, "row pitch smaller than one frame of this plan's bins");
+    if (!p->X_owned) HIP_TRY(hipMalloc(&p->X_owned, row * p->T));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy2D(p->X_owned, row, X, pitch, row, p->T, hipMemcpyHostToDevice));
+    p->X = p->X_owned;
+    p->have_x = true;
+    p->have_cx = false;
+    return OIVA_OK;
+}
+
+int oiva_plan_set_x_dev(oiva_plan* p, const void* X_dev) {
+    NEED(p && X_dev, OIVA_ERR_ARG, "null argument");
+    NEED(((uintptr_t)X_dev & 15) == 0, OIVA_ERR_ARG, "device X must be 16-byte aligned");
+    p->X = (const float2*)X_dev;
+    p->have_x = true;
+    p->have_cx = false;
+    return OIVA_OK;
+}
+
+int oiva_plan_covariance(oiva_plan* p) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(p->have_x, OIVA_ERR_STATE, "X not set");
+    DeviceGuard guard(p->device);
+    CovGeom g = p->cov;
+    g.kc = 1;
+    // unit weights, one "source": partials land in Vpart laid out as [nsplit][F][1][M*M]
+    HIP_TRY(launch_cov(p->stream, p->X, nullptr, p->Vpart, p->T, p->F, p->M, 1, g));
+    HIP_TRY(launch_sum_parts(p->stream, p->Vpart, g.nsplit, p->Cx, (long long)p->F * p->M * p->M, 1.f / (float)p->T));
+    p->have_cx = true;
+    return OIVA_OK;
+}
+
+int oiva_plan_get_cx(oiva_plan* p, void* Cx_host) {
+    NEED(p && Cx_host, OIVA_ERR_ARG, "null argument");
+    NEED(p->have_cx, OIVA_ERR_STATE, "input covariance not computed");
+    DeviceGuard guard(p->device);
+    HIP_TRY(launch_unpack_herm(p->stream, p->Cx, p->scratch_c, p->F, p->M, 1.f));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(Cx_host, p->scratch_c, (size_t)p->F * p->M * p->M * sizeof(float2), hipMemcpyDeviceToHost));
+    return OIVA_OK;
+}
+
+int oiva_plan_set_w(oiva_plan* p, const void* W0_host) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(p->have_cx, OIVA_ERR_STATE, "input covariance not computed (needed for the orthogonality constraint)");
+    DeviceGuard guard(p->device);
+    const int F = p->F, M = p->M, K = p->K;
+    std::vector<float2> wh((size_t)F * M * M, make_float2(0.f, 0.f));
+    const float2* w0 = (const float2*)W0_host;
+    for (int f = 0; f < F; ++f) {
+        float2* m = wh.data() + (size_t)f * M * M;
+        for (int r = 0; r < M; ++r)
+            for (int k = 0; k < K; ++k)
+                m[r * M + k] = w0 ? w0[((size_t)f * M + r) * K + k] : make_float2(r == k ? 1.f : 0.f, 0.f);
+        for (int r = K; r < M; ++r) m[r * M + r] = make_float2(-1.f, 0.f);  // overiva.py:122-123
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(p->What, wh.data(), wh.size() * sizeof(float2), hipMemcpyHostToDevice));
+    p->wscale_pending = false;
+    p->have_w = true;
+    if (K < M) return stage_update(p, true);  // J from the orthogonality constraint, overiva.py:120-121
+    return OIVA_OK;
+}
+
+int oiva_plan_iterate(oiva_plan* p, int n) {
+    int rc = check_ready(p);
+    if (rc) return rc;
+    NEED(n >= 0, OIVA_ERR_ARG, "negative iteration count");
+    NEED(p->F == p->F_total, OIVA_ERR_STATE,
+         "plan owns a bin shard: drive it with oiva_plan_power / all-gather / oiva_plan_update");
+    DeviceGuard guard(p->device);
+    if (n == 0) return OIVA_OK;
+    if (p->use_graph) {
+        if (!p->graph_exec) {
+            // the update inside the graph always consumes wscale (rfin runs before it in every iteration)
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+            rc = one_iteration(p);
+            hipError_t e = hipStreamEndCapture(p->stream, &graph);
+            if (rc) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
+            HIP_TRY(e);
+            e = hipGraphInstantiate(&p->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            HIP_TRY(e);
+        }
+        for (int i = 0; i < n; ++i) HIP_TRY(hipGraphLaunch(p->graph_exec, p->stream));
+        p->wscale_pending = false;
+        return OIVA_OK;
+    }
+    for (int i = 0; i < n; ++i)
+        if ((rc = one_iteration(p))) return rc;
+    return OIVA_OK;
+}
+
+int oiva_plan_power(oiva_plan* p) {
+    int rc = check_ready(p);
+    if (rc) return rc;
+    DeviceGuard guard(p->device);
+    if ((rc = stage_power(p))) return rc;
+    HIP_TRY(launch_sum_parts(p->stream, p->Ppart, p->pw.nb, p->Plocal, (long long)p->T * p->K, 1.f));
+    return OIVA_OK;
+}
+
+int oiva_plan_power_buffer(oiva_plan* p, void** p_local_dev, long long* bytes) {
+    NEED(p && p_local_dev, OIVA_ERR_ARG, "null argument");
+    *p_local_dev = p->Plocal;
+    if (bytes) *bytes = (long long)p->T * p->K * (long long)sizeof(float);
+    return OIVA_OK;
+}
+
+int oiva_plan_update(oiva_plan* p, const void* parts_dev, int nparts) {
+    int rc = check_ready(p);
+    if (rc) return rc;
+    NEED(parts_dev && nparts >= 1, OIVA_ERR_ARG, "need at least one part");
+    DeviceGuard guard(p->device);
+    if ((rc = stage_rsum(p, (const float*)parts_dev, nparts))) return rc;
+    if ((rc = stage_rfin(p))) return rc;
+    if ((rc = stage_cov(p))) return rc;
+    return stage_update(p, false);
+}
+
+int oiva_plan_demix(oiva_plan* p, void* Y_host, long long row_pitch_bytes, int proj_back) {
+    int rc = check_ready(p);
+    if (rc) return rc;
+    NEED(Y_host, OIVA_ERR_ARG, "null output");
+    DeviceGuard guard(p->device);
+    const size_t row = (size_t)p->F * p->K * sizeof(float2);
+    const size_t pitch = row_pitch_bytes > 0 ? (size_t)row_pitch_bytes : row;
+    NEED(pitch >= row, OIVA_ERR_ARG, "row pitch smaller than one frame of this plan's bins");
+    if (!p->Y) HIP_TRY(hipMalloc(&p->Y, row * p->T));
+    const float* sp = nullptr;
+    if (proj_back) {
+        HIP_TRY(launch_demix_stats(p->stream, p->X, p->What, p->Spart, p->T, p->F, p->M, p->K, p->cov));
+        sp = p->Spart;
+    }
+    HIP_TRY(launch_demix_write(p->stream, p->X, p->What, sp, p->cov.nsplit, p->Y, p->T, p->F, p->M, p->K));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy2D(Y_host, pitch, p->Y, row, row, p->T, hipMemcpyDeviceToHost));
+    return OIVA_OK;
+}
+
+int oiva_plan_get_w(oiva_plan* p, void* W_host) {
+    NEED(p && W_host, OIVA_ERR_ARG, "null argument");
+    NEED(p->have_w, OIVA_ERR_STATE, "demixing matrix not set");
+    DeviceGuard guard(p->device);
+    const int F = p->F, M = p->M, K = p->K;
+    std::vector<float2> wh((size_t)F * M * M);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(wh.data(), p->What, wh.size() * sizeof(float2), hipMemcpyDeviceToHost));
+    float2* w = (float2*)W_host;
+    bool finite = true;
+    for (int f = 0; f < F; ++f)
+        for (int r = 0; r < M; ++r)
+            for (int k = 0; k < K; ++k) {
+                const float2 v = wh[((size_t)f * M + r) * M + k];
+                finite = finite && std::isfinite(v.x) && std::isfinite(v.y);
+                w[((size_t)f * M + r) * K + k] = v;
+            }
+    if (!finite) return fail(OIVA_ERR_NUMERIC, "demixing matrix holds non-finite values (singular W_hat^H V)");
+    return OIVA_OK;
+}
+
+int oiva_plan_sync(oiva_plan* p) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return OIVA_OK;
+}
+
+int oiva_plan_iterate_timed(oiva_plan* p, int n, float* total_ms, float* per_kernel_ms) {
+    int rc = check_ready(p);
+    if (rc) return rc;
+    NEED(n >= 1 && total_ms, OIVA_ERR_ARG, "bad arguments");
+    NEED(p->F == p->F_total, OIVA_ERR_STATE, "timed iterate needs a plan that owns all bins");
+    DeviceGuard guard(p->device);
+    hipEvent_t e_begin = p->ev[0], e_end = p->ev[1];
+    if (!per_kernel_ms) {
+        HIP_TRY(hipEventRecord(e_begin, p->stream));
+        if ((rc = oiva_plan_iterate(p, n))) return rc;
+        HIP_TRY(hipEventRecord(e_end, p->stream));
+        HIP_TRY(hipEventSynchronize(e_end));
+        HIP_TRY(hipEventElapsedTime(total_ms, e_begin, e_end));
+        return OIVA_OK;
+    }
+    // per-kernel: an event before every launch and one after the last launch of each iteration, all
+    // recorded without draining the stream; elapsed times are read after one final synchronisation.
+    for (int s = 0; s < OIVA_N_STAGES; ++s) per_kernel_ms[s] = 0.f;
+    *total_ms = 0.f;
+    const int per_it = OIVA_N_STAGES + 1;
+    std::vector<hipEvent_t> pool((size_t)n * per_it, nullptr);
+    auto destroy = [&]() {
+        for (hipEvent_t e : pool)
+            if (e) (void)hipEventDestroy(e);
+    };
+    for (auto& e : pool) {
+        hipError_t err = hipEventCreate(&e);
+        if (err != hipSuccess) {
+            destroy();
+            return fail(OIVA_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(err));
+        }
+    }
+    hipError_t err = hipSuccess;
+    for (int it = 0; it < n && err == hipSuccess && rc == OIVA_OK; ++it) {
+        hipEvent_t* e = pool.data() + (size_t)it * per_it;
+        err = hipEventRecord(e[0], p->stream);
+        if (err == hipSuccess && !(rc = stage_power(p))) err = hipEventRecord(e[1], p->stream);
+        if (err == hipSuccess && !rc && !(rc = stage_rsum(p, p->Ppart, p->pw.nb))) err = hipEventRecord(e[2], p->stream);
+        if (err == hipSuccess && !rc && !(rc = stage_rfin(p))) err = hipEventRecord(e[3], p->stream);
+        if (err == hipSuccess && !rc && !(rc = stage_cov(p))) err = hipEventRecord(e[4], p->stream);
+        if (err == hipSuccess && !rc && !(rc = stage_update(p, false))) err = hipEventRecord(e[5], p->stream);
+    }
+    if (err == hipSuccess && rc == OIVA_OK) err = hipStreamSynchronize(p->stream);
+    for (int it = 0; it < n && err == hipSuccess && rc == OIVA_OK; ++it) {
+        hipEvent_t* e = pool.data() + (size_t)it * per_it;
+        for (int s = 0; s < OIVA_N_STAGES && err == hipSuccess; ++s) {
+            float ms = 0.f;
+            err = hipEventElapsedTime(&ms, e[s], e[s + 1]);
+            per_kernel_ms[s] += ms;
+        }
+    }
+    if (err == hipSuccess && rc == OIVA_OK) err = hipEventElapsedTime(total_ms, pool[0], pool[(size_t)n * per_it - 1]);
+    destroy();
+    if (rc) return rc;
+    HIP_TRY(err);
+    return OIVA_OK;
+}
+
+int oiva_plan_get_cov_splits(oiva_plan* p, int* nsplit) {
+    NEED(p && nsplit, OIVA_ERR_ARG, "null argument");
+    *nsplit = p->cov.nsplit;
+    return OIVA_OK;
+}
+
+int oiva_plan_set_cov_splits(oiva_plan* p, int nsplit) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(nsplit >= 0 && nsplit <= p->T, OIVA_ERR_ARG, "bad split count");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    int rc = drop_graph(p);
+    if (rc) return rc;
+    choose_cov_geom(p, nsplit);
+    return ensure_vpart(p);
+}
+
+int oiva_plan_use_graph(oiva_plan* p, int enable) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    DeviceGuard guard(p->device);
+    p->use_graph = enable ? 1 : 0;
+    if (!enable) return drop_graph(p);
+    return OIVA_OK;
+}
+
+int oiva_plan_set_precision(oiva_plan* p, int fp64_update) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    int rc = drop_graph(p);
+    if (rc) return rc;
+    p->use_double = fp64_update ? 1 : 0;
+    return OIVA_OK;
+}
+
+// ---- test-only stage access -----------------------------------------------------------------------
+int oiva_test_set_rinv(oiva_plan* p, const float* rinv_host) {
+    NEED(p && rinv_host, OIVA_ERR_ARG, "null argument");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(p->Rinv, rinv_host, (size_t)p->T * p->K * sizeof(float), hipMemcpyHostToDevice));
+    return OIVA_OK;
+}
+
+int oiva_test_get_rinv(oiva_plan* p, float* rinv_host, float* wscale_host) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (rinv_host)
+        HIP_TRY(hipMemcpy(rinv_host, p->Rinv, (size_t)p->T * p->K * sizeof(float), hipMemcpyDeviceToHost));
+    if (wscale_host) HIP_TRY(hipMemcpy(wscale_host, p->wscale, (size_t)p->K * sizeof(float), hipMemcpyDeviceToHost));
+    return OIVA_OK;
+}
+
+int oiva_test_run_weighted_cov(oiva_plan* p) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(p->have_x, OIVA_ERR_STATE, "X not set");
+    DeviceGuard guard(p->device);
+    return stage_cov(p);
+}
+
+int oiva_test_get_v(oiva_plan* p, void* V_host) {
+    NEED(p && V_host, OIVA_ERR_ARG, "null argument");
+    DeviceGuard guard(p->device);
+    const int F = p->F, M = p->M, K = p->K;
+    const long long nfk = (long long)F * K * M * M;
+    float* packed = nullptr;
+    HIP_TRY(hipMalloc(&packed, nfk * sizeof(float)));
+    hipError_t e = launch_sum_parts(p->stream, p->Vpart, p->cov.nsplit, packed, nfk, 1.f / (float)p->T);
+    if (e == hipSuccess) e = launch_unpack_herm(p->stream, packed, p->scratch_c, (long long)F * K, M, 1.f);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    std::vector<float2> fk((size_t)nfk);
+    if (e == hipSuccess) e = hipMemcpy(fk.data(), p->scratch_c, fk.size() * sizeof(float2), hipMemcpyDeviceToHost);
+    (void)hipFree(packed);
+    HIP_TRY(e);
+    // device order is [F][K][M][M]; the oracle's is (K, F, M, M)
+    float2* out = (float2*)V_host;
+    const size_t mm = (size_t)M * M;
+    for (int f = 0; f < F; ++f)
+        for (int k = 0; k < K; ++k)
+            std::memcpy(out + ((size_t)k * F + f) * mm, fk.data() + ((size_t)f * K + k) * mm, mm * sizeof(float2));
+    return OIVA_OK;
+}
+
+int oiva_test_run_update(oiva_plan* p) {
+    int rc = check_ready(p);
+    if (rc) return rc;
+    DeviceGuard guard(p->device);
+    return stage_update(p, false);
+}
+
+int oiva_test_get_what(oiva_plan* p, void* What_host) {
+    NEED(p && What_host, OIVA_ERR_ARG, "null argument");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(What_host, p->What, (size_t)p->F * p->M * p->M * sizeof(float2), hipMemcpyDeviceToHost));
+    return OIVA_OK;
+}
+
+int oiva_test_set_what(oiva_plan* p, const void* What_host) {
+    NEED(p && What_host, OIVA_ERR_ARG, "null argument");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(p->What, What_host, (size_t)p->F * p->M * p->M * sizeof(float2), hipMemcpyHostToDevice));
+    p->have_w = true;
+    p->wscale_pending = false;
+    return OIVA_OK;
+}
+
+int oiva_test_run_power(oiva_plan* p, float* p_host) {
+    NEED(p && p_host, OIVA_ERR_ARG, "null argument");
+    NEED(p->have_x && p->have_w, OIVA_ERR_STATE, "X / W not set");
+    DeviceGuard guard(p->device);
+    int rc = stage_power(p);
+    if (rc) return rc;
+    HIP_TRY(launch_sum_parts(p->stream, p->Ppart, p->pw.nb, p->Plocal, (long long)p->T * p->K, 1.f));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(p_host, p->Plocal, (size_t)p->T * p->K * sizeof(float), hipMemcpyDeviceToHost));
+    return OIVA_OK;
+}
+
+}  // extern "C"

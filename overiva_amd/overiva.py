@@ -1,0 +1,169 @@
+"""Drop-in ``overiva()`` -- same name, argument order, defaults and return values as reference
+``overiva.py:28-38``; the body runs on one MI355X (or bin-sharded over several, see ``sharded.py``).
+
+Documented deviations from the reference:
+* arithmetic is float32/complex64 on the device whatever the input dtype; the result is cast back
+  to the input's complex dtype (the reference computes in the input dtype, ``overiva.py:89,126,131``);
+* an unknown ``model`` raises ``ValueError`` (the reference silently returns NaN, ``overiva.py:152-167``);
+* the returned ``W`` is a fresh contiguous ``(n_freq, n_chan, n_src)`` array, not a view of ``W_hat``
+  (``overiva.py:90,201-202``).
+"""
+import os
+
+import numpy as np
+
+from . import sharded
+from .plan import Plan
+
+_device = None
+
+
+def set_device(index):
+    """GPU used by subsequent calls in this process (default: $LOCAL_RANK, else 0)."""
+    global _device
+    _device = int(index)
+
+
+def get_device():
+    if _device is not None:
+        return _device
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def _complex_dtype(X):
+    if X.dtype == np.complex64 or X.dtype == np.complex128:
+        return X.dtype
+    if np.issubdtype(X.dtype, np.complexfloating):
+        return np.dtype(np.complex128)
+    raise TypeError(f"X must be a complex STFT array, got dtype {X.dtype}")
+
+
+def eig_init(Cx, n_src):
+    """W0 from the principal eigenvectors of the input covariance (reference overiva.py:106-109).
+
+    Stays on the host: eigenvector phases are LAPACK's choice and the reference keeps them.
+    """
+    vals, vecs = np.linalg.eig(Cx.astype(np.complex128))
+    F, M, _ = Cx.shape
+    W0 = np.empty((F, M, n_src), dtype=np.complex128)
+    for f in range(F):
+        keep = np.argsort(vals[f])[-n_src:]
+        W0[f] = np.conj(vecs[f][:, keep])
+    return W0
+
+
+def overiva(
+    X,
+    n_src=None,
+    n_iter=20,
+    proj_back=True,
+    W0=None,
+    model="laplace",
+    init_eig=False,
+    return_filters=False,
+    callback=None,
+):
+    """
+    Overdetermined IVA / AuxIVA (Scheibler & Ono 2019) on the GPU.
+
+    Parameters
+    ----------
+    X: ndarray (nframes, nfrequencies, nchannels)
+        STFT representation of the signal
+    n_src: int, optional
+        Number of sources; ``n_src == nchannels`` (default) is plain AuxIVA
+    n_iter: int, optional
+        Number of iterations (default 20)
+    proj_back: bool, optional
+        Scale by projection back onto the first channel (default True)
+    W0: ndarray broadcastable to (nfrequencies, nchannels, nsrc), optional
+        Initial demixing vectors (columns)
+    model: str
+        'laplace' (default) or 'gauss'
+    init_eig: bool, optional
+        Initialise from the principal eigenvectors of the input covariance when ``W0 is None``
+    return_filters: bool
+        Also return the demixing matrix (nfrequencies, nchannels, nsrc)
+    callback: func
+        Called with the current (nframes, nfrequencies, nsrc) estimate at epochs 0, 10, 20, ...
+
+    Returns
+    -------
+    Y (nframes, nfrequencies, nsrc) in the dtype of X, or ``(Y, W)`` if ``return_filters``.
+    """
+    X = np.asarray(X)
+    if X.ndim != 3:
+        raise ValueError("X must have shape (n_frames, n_freq, n_chan)")
+    dtype = _complex_dtype(X)
+    n_frames, n_freq, n_chan = X.shape
+    if n_src is None:  # default to the determined case, overiva.py:83-84
+        n_src = n_chan
+    if not 1 <= n_src <= n_chan:
+        raise ValueError(f"n_src must be in 1..{n_chan}")
+    if model not in ("laplace", "gauss"):
+        raise ValueError(f"model must be 'laplace' or 'gauss', got {model!r}")
+    if n_iter < 0:
+        raise ValueError("n_iter must be >= 0")
+
+    group = sharded.active_group()
+    if group is not None:
+        solver = sharded.BinShardedSolver(n_frames, n_freq, n_chan, n_src, model, group=group[0])
+    else:
+        solver = _SingleDevice(n_frames, n_freq, n_chan, n_src, model)
+    try:
+        solver.set_x(X)
+        solver.covariance()
+        if W0 is None and init_eig:
+            W0 = eig_init(solver.get_cx(), n_src)
+        solver.set_w(W0)
+
+        epoch = 0
+        while epoch < n_iter:
+            if callback is not None and epoch % 10 == 0:  # overiva.py:142-148
+                callback(solver.demix(proj_back).astype(dtype, copy=False))
+            if callback is None:
+                step = n_iter - epoch
+            else:
+                step = min(n_iter - epoch, 10 - epoch % 10)
+            solver.iterate(step)
+            epoch += step
+
+        Y = solver.demix(proj_back).astype(dtype, copy=False)
+        if return_filters:
+            return Y, solver.get_w().astype(dtype, copy=False)
+        # surface a singular solve the way numpy.linalg.solve would (overiva.py:182)
+        solver.get_w()
+        return Y
+    finally:
+        solver.close()
+
+
+class _SingleDevice:
+    """all bins on one GPU"""
+
+    def __init__(self, T, F, M, K, model):
+        self.plan = Plan(T, F, M, K, model, device=get_device())
+
+    def set_x(self, X):
+        self.plan.set_x(X)
+
+    def covariance(self):
+        self.plan.covariance()
+
+    def get_cx(self):
+        return self.plan.get_cx()
+
+    def set_w(self, W0):
+        self.plan.set_w(W0)
+
+    def iterate(self, n):
+        self.plan.iterate(n)
+
+    def demix(self, proj_back):
+        return self.plan.demix(proj_back)
+
+    def get_w(self):
+        return self.plan.get_w()
+
+    def close(self):
+        self.plan.close()

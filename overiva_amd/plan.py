@@ -1,0 +1,179 @@
+"""Python face of one ``oiva_plan`` (one GPU, one stream, one contiguous range of frequency bins)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class Plan:
+    """Owns the device state of one AuxIVA/OverIVA problem (or one bin shard of it).
+
+    Mirrors the stages of reference ``overiva.py``: ``set_x`` (:132), ``covariance`` (:87),
+    ``set_w`` (:89-123), ``iterate`` (:138-190), ``demix`` (:192-199), ``get_w`` (:201-202).
+    """
+
+    def __init__(self, T, F, M, K, model="laplace", device=0, F_total=None, stream=None):
+        if model not in _lib.MODEL_IDS:
+            # the reference silently produces NaN for an unknown model (overiva.py:152-167)
+            raise ValueError(f"model must be 'laplace' or 'gauss', got {model!r}")
+        self.lib = _lib.load()
+        self.T, self.F, self.M, self.K = int(T), int(F), int(M), int(K)
+        self.model = model
+        self.F_total = int(F if F_total is None else F_total)
+        self.device = int(device)
+        h = C.c_void_p()
+        _lib.check(self.lib.oiva_plan_create(C.byref(h), self.device, self.T, self.F, self.M, self.K,
+                                             _lib.MODEL_IDS[model], self.F_total,
+                                             C.c_void_p(stream) if stream else None))
+        self.h = h
+        self._keep = None
+
+    # -- life cycle ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.oiva_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- input --------------------------------------------------------------------------------
+    def set_x(self, X, f0=0):
+        """X: (T, F_any, M) complex host array; uploads bins [f0, f0+F) as complex64."""
+        X = np.asarray(X)
+        if X.ndim != 3 or X.shape[0] != self.T or X.shape[2] != self.M or X.shape[1] < f0 + self.F:
+            raise ValueError(f"X has shape {X.shape}, plan expects ({self.T}, >={f0 + self.F}, {self.M})")
+        if X.dtype != np.complex64 or not X.flags["C_CONTIGUOUS"]:
+            X = np.ascontiguousarray(X[:, f0:f0 + self.F, :], dtype=np.complex64)
+            f0 = 0
+        pitch = X.shape[1] * self.M * 8
+        base = X.ctypes.data + f0 * self.M * 8
+        _lib.check(self.lib.oiva_plan_set_x_host(self.h, C.c_void_p(base), pitch))
+
+    def set_x_device(self, dev_ptr, keepalive=None):
+        """Borrow a dense (T, F, M) complex64 device array (e.g. a torch tensor's data_ptr())."""
+        self._keep = keepalive
+        _lib.check(self.lib.oiva_plan_set_x_dev(self.h, C.c_void_p(int(dev_ptr))))
+
+    # -- prologue -----------------------------------------------------------------------------
+    def covariance(self):
+        _lib.check(self.lib.oiva_plan_covariance(self.h))
+
+    def get_cx(self):
+        out = np.empty((self.F, self.M, self.M), np.complex64)
+        _lib.check(self.lib.oiva_plan_get_cx(self.h, _lib.ptr(out)))
+        return out
+
+    def set_w(self, W0=None):
+        if W0 is None:
+            _lib.check(self.lib.oiva_plan_set_w(self.h, None))
+            return
+        W0 = np.ascontiguousarray(np.broadcast_to(np.asarray(W0), (self.F, self.M, self.K)), dtype=np.complex64)
+        _lib.check(self.lib.oiva_plan_set_w(self.h, _lib.ptr(W0)))
+
+    # -- iteration ----------------------------------------------------------------------------
+    def iterate(self, n=1):
+        _lib.check(self.lib.oiva_plan_iterate(self.h, int(n)))
+
+    def power(self):
+        _lib.check(self.lib.oiva_plan_power(self.h))
+
+    def power_buffer(self):
+        p, nbytes = C.c_void_p(), C.c_longlong()
+        _lib.check(self.lib.oiva_plan_power_buffer(self.h, C.byref(p), C.byref(nbytes)))
+        return p.value, nbytes.value
+
+    def update(self, parts_dev_ptr, nparts):
+        _lib.check(self.lib.oiva_plan_update(self.h, C.c_void_p(int(parts_dev_ptr)), int(nparts)))
+
+    def iterate_timed(self, n, per_kernel=False):
+        total = C.c_float()
+        if per_kernel:
+            arr = (C.c_float * _lib.N_STAGES)()
+            _lib.check(self.lib.oiva_plan_iterate_timed(self.h, int(n), C.byref(total), arr))
+            return total.value, dict(zip(_lib.STAGE_NAMES, list(arr)))
+        _lib.check(self.lib.oiva_plan_iterate_timed(self.h, int(n), C.byref(total), None))
+        return total.value, None
+
+    # -- epilogue -----------------------------------------------------------------------------
+    def demix(self, proj_back=True, out=None, f0=0):
+        """Y (T, F, K) complex64; with ``out`` (T, F_any, K) writes bins [f0, f0+F) in place."""
+        if out is None:
+            out = np.empty((self.T, self.F, self.K), np.complex64)
+            f0 = 0
+        assert out.dtype == np.complex64 and out.flags["C_CONTIGUOUS"]
+        pitch = out.shape[1] * self.K * 8
+        base = out.ctypes.data + f0 * self.K * 8
+        _lib.check(self.lib.oiva_plan_demix(self.h, C.c_void_p(base), pitch, 1 if proj_back else 0))
+        return out
+
+    def get_w(self):
+        out = np.empty((self.F, self.M, self.K), np.complex64)
+        _lib.check(self.lib.oiva_plan_get_w(self.h, _lib.ptr(out)))
+        return out
+
+    def sync(self):
+        _lib.check(self.lib.oiva_plan_sync(self.h))
+
+    # -- knobs --------------------------------------------------------------------------------
+    def cov_splits(self):
+        n = C.c_int()
+        _lib.check(self.lib.oiva_plan_get_cov_splits(self.h, C.byref(n)))
+        return n.value
+
+    def set_cov_splits(self, n):
+        _lib.check(self.lib.oiva_plan_set_cov_splits(self.h, int(n)))
+
+    def use_graph(self, enable=True):
+        _lib.check(self.lib.oiva_plan_use_graph(self.h, 1 if enable else 0))
+
+    def set_precision(self, fp64_update):
+        _lib.check(self.lib.oiva_plan_set_precision(self.h, 1 if fp64_update else 0))
+
+    # -- test-only stage access -----------------------------------------------------------------
+    def t_set_rinv(self, rinv):
+        rinv = np.ascontiguousarray(rinv, dtype=np.float32)
+        assert rinv.shape == (self.T, self.K)
+        _lib.check(self.lib.oiva_test_set_rinv(self.h, _lib.ptr(rinv)))
+
+    def t_get_rinv(self):
+        r = np.empty((self.T, self.K), np.float32)
+        w = np.empty((self.K,), np.float32)
+        _lib.check(self.lib.oiva_test_get_rinv(self.h, _lib.ptr(r), _lib.ptr(w)))
+        return r, w
+
+    def t_run_weighted_cov(self):
+        _lib.check(self.lib.oiva_test_run_weighted_cov(self.h))
+
+    def t_get_v(self):
+        v = np.empty((self.K, self.F, self.M, self.M), np.complex64)
+        _lib.check(self.lib.oiva_test_get_v(self.h, _lib.ptr(v)))
+        return v
+
+    def t_run_update(self):
+        _lib.check(self.lib.oiva_test_run_update(self.h))
+
+    def t_get_what(self):
+        w = np.empty((self.F, self.M, self.M), np.complex64)
+        _lib.check(self.lib.oiva_test_get_what(self.h, _lib.ptr(w)))
+        return w
+
+    def t_set_what(self, What):
+        What = np.ascontiguousarray(What, dtype=np.complex64)
+        assert What.shape == (self.F, self.M, self.M)
+        _lib.check(self.lib.oiva_test_set_what(self.h, _lib.ptr(What)))
+
+    def t_run_power(self):
+        p = np.empty((self.T, self.K), np.float32)
+        _lib.check(self.lib.oiva_test_run_power(self.h, _lib.ptr(p)))
+        return p

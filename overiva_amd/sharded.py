@@ -1,0 +1,195 @@
+"""Frequency-bin sharding over the GPUs of one node (one process per GPU, torch.distributed).
+
+Every per-iteration quantity of the algorithm is per-bin except the source activation
+``r[t,k] = f(sum_f |y_{t,f,k}|^2)`` (reference ``overiva.py:152-155``).  Each rank therefore owns a
+contiguous range of bins end to end (its slice of X, Cx, V, W_hat, Y never leaves its GPU) and one
+collective per iteration exchanges the per-rank partial powers: an all-gather of (T, K) float32
+followed by a sum in rank order on every rank (bitwise identical ``r`` everywhere; an all-reduce
+would leave the order to the ring).  With backend "nccl" this is RCCL over xGMI; the payload is
+tiny (T*K*4 bytes per rank), so the step is latency bound.
+
+torch is plumbing here (process group, the exchange buffers, the current stream); the arithmetic is
+in the HIP kernels behind ``Plan``.  The engine is injectable so that the N > 1 control flow can be
+exercised on CPU with the gloo backend in tests (``tests/test_sharded_gloo.py`` supplies an
+oracle-backed engine; the product never does).
+"""
+import numpy as np
+
+_active = None  # (group,) when overiva() should shard
+
+
+def enable_bin_sharding(group=None):
+    """Make ``overiva()`` shard bins over the ranks of ``group`` (default: the world group).
+    Every rank must then call ``overiva()`` with the same arguments; every rank gets the full result."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised")
+    global _active
+    _active = (group,)
+
+
+def disable_bin_sharding():
+    global _active
+    _active = None
+
+
+def active_group():
+    return _active
+
+
+def shard_bounds(n_freq, world):
+    """bins [b[r], b[r+1]) belong to rank r; sizes differ by at most one"""
+    return [n_freq * r // world for r in range(world + 1)]
+
+
+class HipEngine:
+    """the product engine: one ``Plan`` on this rank's GPU, launched on torch's current stream"""
+
+    def __init__(self, T, F_local, M, K, model, F_total, device):
+        import torch
+
+        from .plan import Plan
+
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        # Kernels and the collective must share one stream so that they are ordered without host
+        # syncs.  torch's default stream has the null handle, which the C ABI reads as "own stream",
+        # so a dedicated torch stream is used unless the caller already switched to one.
+        cur = torch.cuda.current_stream(self.device)
+        self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(device=self.device)
+        self.plan = Plan(T, F_local, M, K, model, device=device, F_total=F_total, stream=self.stream.cuda_stream)
+        self.T, self.K = T, K
+
+    def stream_ctx(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def exchange_buffer(self):
+        """(T, K) float32 device tensor aliasing the plan's local-power buffer"""
+        ptr, nbytes = self.plan.power_buffer()
+
+        class _Mem:
+            pass
+
+        m = _Mem()
+        m.__cuda_array_interface__ = {"shape": (self.T, self.K), "typestr": "<f4", "data": (ptr, False),
+                                      "version": 2, "strides": None}
+        t = self.torch.as_tensor(m, device=self.device)
+        assert t.data_ptr() == ptr, "torch copied the exchange buffer instead of aliasing it"
+        return t
+
+    def new_gather_buffer(self, world):
+        # rank-major concatenation along dim 0 == (world, T, K) in memory (the layout every backend accepts)
+        return self.torch.empty((world * self.T, self.K), dtype=self.torch.float32, device=self.device)
+
+    def set_x(self, X, f0):
+        self.plan.set_x(X, f0)
+
+    def set_x_device(self, ptr, keepalive=None):
+        self.plan.set_x_device(ptr, keepalive)
+
+    def covariance(self):
+        self.plan.covariance()
+
+    def get_cx(self):
+        return self.plan.get_cx()
+
+    def set_w(self, W0):
+        self.plan.set_w(W0)
+
+    def power(self):
+        self.plan.power()
+
+    def update(self, parts):
+        self.plan.update(parts.data_ptr(), parts.shape[0] // self.T)
+
+    def demix(self, proj_back):
+        return self.plan.demix(proj_back)
+
+    def get_w(self):
+        return self.plan.get_w()
+
+    def to_comm(self, a):
+        return self.torch.from_numpy(a).to(self.device)
+
+    def sync(self):
+        self.plan.sync()
+
+    def close(self):
+        self.plan.close()
+
+
+class BinShardedSolver:
+    """Same stage interface as the single-GPU solver in ``overiva.py``, over a process group."""
+
+    def __init__(self, T, F, M, K, model, group=None, engine_factory=None, device=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        if F < self.world:
+            raise ValueError("fewer frequency bins than ranks")
+        self.T, self.F, self.M, self.K = T, F, M, K
+        self.bounds = shard_bounds(F, self.world)
+        self.f0, self.f1 = self.bounds[self.rank], self.bounds[self.rank + 1]
+        if engine_factory is None:
+            from .overiva import get_device
+
+            dev = get_device() if device is None else device
+            self.engine = HipEngine(T, self.f1 - self.f0, M, K, model, F, dev)
+        else:
+            self.engine = engine_factory(T, self.f1 - self.f0, M, K, model, F)
+        self.p_local = self.engine.exchange_buffer()
+        self.p_all = self.engine.new_gather_buffer(self.world)
+
+    # ---- stages ---------------------------------------------------------------------------------
+    def set_x(self, X):
+        self.engine.set_x(X, self.f0)
+
+    def covariance(self):
+        self.engine.covariance()
+
+    def get_cx(self):
+        return self._gather_bins(self.engine.get_cx(), axis=0)
+
+    def set_w(self, W0):
+        if W0 is not None:
+            W0 = np.broadcast_to(np.asarray(W0), (self.F, self.M, self.K))[self.f0:self.f1]
+        self.engine.set_w(W0)
+
+    def iterate(self, n):
+        with self.engine.stream_ctx():
+            for _ in range(n):
+                self.engine.power()                                # local sum_f |y|^2 -> p_local
+                self.dist.all_gather_into_tensor(self.p_all, self.p_local, group=self.group)
+                self.engine.update(self.p_all)                     # rank-order sum, r, V, IP1, J
+
+    def demix(self, proj_back):
+        return self._gather_bins(self.engine.demix(proj_back), axis=1)
+
+    def get_w(self):
+        return self._gather_bins(self.engine.get_w(), axis=0)
+
+    def close(self):
+        self.engine.close()
+
+    # ---- helpers --------------------------------------------------------------------------------
+    def _gather_bins(self, local, axis):
+        """concatenate per-rank complex64 arrays along the bin axis on every rank"""
+        import torch
+
+        local = np.ascontiguousarray(np.moveaxis(local, axis, 0))          # (F_local, ...)
+        rest = local.shape[1:]
+        fmax = max(self.bounds[r + 1] - self.bounds[r] for r in range(self.world))
+        pad = np.zeros((fmax,) + rest, dtype=np.complex64)
+        pad[: local.shape[0]] = local
+        send = self.engine.to_comm(pad.view(np.float32))
+        recv = torch.empty((self.world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype,
+                           device=send.device)
+        self.dist.all_gather_into_tensor(recv, send, group=self.group)
+        full = recv.cpu().numpy().view(np.complex64).reshape((self.world, fmax) + rest)
+        parts = [full[r, : self.bounds[r + 1] - self.bounds[r]] for r in range(self.world)]
+        return np.moveaxis(np.concatenate(parts, axis=0), 0, axis)

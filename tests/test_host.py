@@ -1,0 +1,123 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/overiva_hip.h declares,
+the ctypes table matches the header, host-side argument handling, and loud failure without a GPU or
+without the built library.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, has_gpu
+
+HEADER = os.path.join(REPO, "include", "overiva_hip.h")
+
+
+def header_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(oiva_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from overiva_amd import build, _lib
+
+    build.build_library()          # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def test_header_declares_the_abi():
+    syms = header_symbols()
+    for must in ("oiva_plan_create", "oiva_plan_iterate", "oiva_plan_power", "oiva_plan_update",
+                 "oiva_plan_demix", "oiva_plan_get_w", "oiva_last_error", "oiva_version"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in header_symbols():
+        assert hasattr(lib, name), f"{name} declared in overiva_hip.h but not exported"
+    assert lib.oiva_version() >= 100
+
+
+def test_ctypes_table_matches_header(lib):
+    from overiva_amd import _lib
+
+    declared = set(header_symbols()) - {"oiva_version", "oiva_last_error"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+
+
+def test_no_torch_types_in_abi():
+    txt = open(HEADER).read()
+    assert "torch" not in txt.lower().replace("pytorch", "") and "at::" not in txt and "std::" not in txt
+
+
+def test_argument_validation_before_device(lib):
+    import overiva_amd as oa
+
+    X = (np.ones((8, 3, 2)) + 0j).astype(np.complex64)
+    with pytest.raises(ValueError):
+        oa.overiva(X, n_src=2, model="student")
+    with pytest.raises(ValueError):
+        oa.overiva(X, n_src=3)
+    with pytest.raises(ValueError):
+        oa.overiva(X, n_src=0)
+    with pytest.raises(TypeError):
+        oa.overiva(X.real)
+    with pytest.raises(ValueError):
+        oa.overiva(X[0])
+    with pytest.raises(KeyError):      # auxiva_pca.py:86 pops 'proj_back' unconditionally
+        oa.auxiva_pca(X, n_src=1, n_iter=1)
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_fails_loudly_without_gpu(lib):
+    """no CPU fallback: without a device the product path raises instead of computing"""
+    import overiva_amd as oa
+
+    X = (np.ones((8, 3, 2)) + 0j).astype(np.complex64)
+    with pytest.raises(oa.HipError):
+        oa.overiva(X, n_src=1, n_iter=1)
+    n = ctypes.c_int()
+    assert lib.oiva_device_count(ctypes.byref(n)) != 0
+    assert b"hipGetDeviceCount" in lib.oiva_last_error()
+
+
+def test_fails_loudly_without_library(monkeypatch):
+    from overiva_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/liboveriva_hip.so")
+    with pytest.raises(_lib.HipLibraryMissing):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "overiva_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_shard_bounds():
+    from overiva_amd import shard_bounds
+
+    for F in (8, 513, 2048, 2049):
+        for G in (1, 2, 3, 4, 8):
+            b = shard_bounds(F, G)
+            assert b[0] == 0 and b[-1] == F and len(b) == G + 1
+            sizes = np.diff(b)
+            assert sizes.min() >= 1 and sizes.max() - sizes.min() <= 1
+
+
+def test_eig_init_matches_reference_recipe():
+    from overiva_amd.overiva import eig_init
+    from oracle import overiva_oracle as orc
+
+    X = orc.synth_iid(64, 5, 4, seed=3).astype(np.complex128)
+    Cx = orc.input_covariance(X)
+    W0 = eig_init(Cx, 2)
+    ref = orc.init_demixing(Cx, 2, init_eig=True)[:, :, :2]
+    assert np.allclose(W0, ref)
