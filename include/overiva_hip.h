@@ -129,8 +129,9 @@ int oiva_plan_get_cov_splits(oiva_plan *p, int *nsplit);
 int oiva_plan_set_cov_splits(oiva_plan *p, int nsplit);
 /* Replay the iteration from a captured hipGraph instead of eager launches (default off). */
 int oiva_plan_use_graph(oiva_plan *p, int enable);
-/* Arithmetic of the per-bin solves: 0 = float32 (default), 1 = float64. */
-int oiva_plan_set_precision(oiva_plan *p, int fp64_update);
+/* Per-bin solve variant: bit 0 = arithmetic (0 float32 (default), 1 float64); bit 1 = lane layout
+ * (0 one lane per matrix element (default for <= 8 channels), 1 one lane per matrix row). */
+int oiva_plan_set_precision(oiva_plan *p, int flags);
 
 /*
  * Test-only stage access (per-kernel parity tests call these through the same ABI).

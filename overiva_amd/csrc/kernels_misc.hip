@@ -21,35 +21,41 @@ __device__ __forceinline__ double block_sum(double v, double* scratch /* [kWaves
     return s;
 }
 
-// R[t,k] = 2 sqrt(p) | p / F_total with p = sum over parts (rank / bin-batch order);
-// Gsum[blk][k] = sum over the block's frames of R
+// R[e] = 2 sqrt(p) | p / F_total with p = sum over parts in part order (bin batch / rank order), e = t*K + k.
+// kRsumLanes lanes share one element: lane l adds parts l, l+8, ...; a fixed shuffle tree adds the lanes.
+constexpr int kRsumLanes = 8;
 __global__ __launch_bounds__(kBlock) void rsum_kernel(const float* __restrict__ parts, int nparts,
-                                                      float* __restrict__ R, double* __restrict__ Gsum, int T, int K,
-                                                      int model, float inv_f_total) {
-    __shared__ double scratch[kWaves];
-    const int t = blockIdx.x * kBlock + threadIdx.x;
-    for (int k = 0; k < K; ++k) {
-        float r = 0.f;
-        if (t < T) {
-            float p = 0.f;
-            for (int i = 0; i < nparts; ++i) p += parts[((size_t)i * T + t) * K + k];
-            r = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(p) : p * inv_f_total;
-            R[(size_t)t * K + k] = r;
-        }
-        const double s = block_sum((double)r, scratch);
-        if (threadIdx.x == 0) Gsum[(size_t)blockIdx.x * K + k] = s;
+                                                      float* __restrict__ R, long long n, int model,
+                                                      float inv_f_total) {
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long e = gid / kRsumLanes;
+    const int l = (int)(gid % kRsumLanes);
+    float p = 0.f;
+    if (e < n) {
+#pragma unroll 4
+        for (int i = l; i < nparts; i += kRsumLanes) p += parts[(size_t)i * n + e];
     }
+#pragma unroll
+    for (int off = 1; off < kRsumLanes; off <<= 1) p += __shfl_xor(p, off, kRsumLanes);
+    if (e < n && l == 0) R[e] = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(p) : p * inv_f_total;
 }
 
-// gamma_k = mean_t R ; Rinv = 1 / max(R / gamma, eps) ; wscale = gamma (laplace) | sqrt(gamma) (gauss)
-__global__ __launch_bounds__(kBlock) void rfin_kernel(const float* __restrict__ R, const double* __restrict__ Gsum,
-                                                      int nblk, float* __restrict__ Rinv, float* __restrict__ wscale,
-                                                      int T, int K, int model) {
+// gamma_k = mean_t R (every block re-reduces the whole (T,K) array in a fixed order: it is a few KB);
+// Rinv = 1 / max(R / gamma, eps) ; wscale = gamma (laplace) | sqrt(gamma) (gauss)
+__global__ __launch_bounds__(kBlock) void rfin_kernel(const float* __restrict__ R, float* __restrict__ Rinv,
+                                                      float* __restrict__ wscale, int T, int K, int model) {
+    __shared__ double scratch[kWaves];
+    __shared__ float gam[OIVA_MAX_CHANNELS];
+    for (int k = 0; k < K; ++k) {
+        double s = 0.;
+        for (int t = threadIdx.x; t < T; t += kBlock) s += (double)R[(size_t)t * K + k];
+        s = block_sum(s, scratch);
+        if (threadIdx.x == 0) gam[k] = (float)(s / (double)T);
+    }
+    __syncthreads();
     const int t = blockIdx.x * kBlock + threadIdx.x;
     for (int k = 0; k < K; ++k) {
-        double g = 0.;
-        for (int i = 0; i < nblk; ++i) g += Gsum[(size_t)i * K + k];
-        const float gamma = (float)(g / (double)T);
+        const float gamma = gam[k];
         if (t < T) {
             float rn = R[(size_t)t * K + k] / gamma;
             rn = rn < kEpsR ? kEpsR : rn;   // NaN stays NaN, as r[r < eps] = eps does in the reference
@@ -96,17 +102,16 @@ __global__ __launch_bounds__(kBlock) void unpack_herm_kernel(const float* __rest
 
 int rsum_blocks(int T) { return (T + kBlock - 1) / kBlock; }
 
-hipError_t launch_rsum(hipStream_t s, const float* parts, int nparts, float* R, double* Gsum, int T, int K, int model,
-                       int F_total) {
-    hipLaunchKernelGGL(rsum_kernel, dim3(rsum_blocks(T)), dim3(kBlock), 0, s, parts, nparts, R, Gsum, T, K, model,
-                       1.f / (float)F_total);
+hipError_t launch_rsum(hipStream_t s, const float* parts, int nparts, float* R, int T, int K, int model, int F_total) {
+    const long long n = (long long)T * K;
+    const long long threads = n * kRsumLanes;
+    hipLaunchKernelGGL(rsum_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, parts, nparts,
+                       R, n, model, 1.f / (float)F_total);
     return hipGetLastError();
 }
 
-hipError_t launch_rfin(hipStream_t s, const float* R, const double* Gsum, float* Rinv, float* wscale, int T, int K,
-                       int model) {
-    hipLaunchKernelGGL(rfin_kernel, dim3(rsum_blocks(T)), dim3(kBlock), 0, s, R, Gsum, rsum_blocks(T), Rinv, wscale, T,
-                       K, model);
+hipError_t launch_rfin(hipStream_t s, const float* R, float* Rinv, float* wscale, int T, int K, int model) {
+    hipLaunchKernelGGL(rfin_kernel, dim3(rsum_blocks(T)), dim3(kBlock), 0, s, R, Rinv, wscale, T, K, model);
     return hipGetLastError();
 }
 

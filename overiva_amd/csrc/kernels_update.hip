@@ -295,6 +295,210 @@ __global__ __launch_bounds__(kBlock) void update_kernel(UpdateArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Square layout for M <= 8: one bin = MP x MP lanes (MP = next power of two >= M), lane (i, j) holds
+// element [i][j] of every matrix.  For M = 8 that is exactly one wavefront per bin, so 2048 bins give
+// 2048 independent waves and each elimination step is O(1) arithmetic per lane: the sequential chain
+// per source is ~MP pivots x (a handful of cross-lane moves + one complex divide + one complex FMA).
+// ---------------------------------------------------------------------------------------------
+template <int MP, typename R>
+struct Sq {
+    static constexpr int G = MP * MP;
+    int i, j, gl;
+    __device__ __forceinline__ Sq(int lane_in_group) : i(lane_in_group / MP), j(lane_in_group % MP), gl(lane_in_group) {}
+    // value held by lane (i, c): same row, column c
+    __device__ __forceinline__ R rowb(R v, int c) const { return __shfl(v, i * MP + c, G); }
+    __device__ __forceinline__ Cx<R> rowb(Cx<R> v, int c) const { return {rowb(v.re, c), rowb(v.im, c)}; }
+    // value held by lane (r, j): same column, row r
+    __device__ __forceinline__ R colb(R v, int r) const { return __shfl(v, r * MP + j, G); }
+    __device__ __forceinline__ Cx<R> colb(Cx<R> v, int r) const { return {colb(v.re, r), colb(v.im, r)}; }
+    // value held by the transposed lane (j, i)
+    __device__ __forceinline__ Cx<R> transp(Cx<R> v) const {
+        return {__shfl(v.re, j * MP + i, G), __shfl(v.im, j * MP + i, G)};
+    }
+    // sum over the rows of a column (every lane of the column gets it)
+    __device__ __forceinline__ R colsum(R v) const {
+#pragma unroll
+        for (int off = MP; off < G; off <<= 1) v += __shfl_xor(v, off, G);
+        return v;
+    }
+    __device__ __forceinline__ R allsum(R v) const {
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, G);
+        return v;
+    }
+    // C = A * B for matrices distributed one element per lane; only the first M rows/cols of the
+    // inner index contribute
+    __device__ __forceinline__ Cx<R> matmul(Cx<R> A, Cx<R> B, int M) const {
+        Cx<R> acc = {R(0), R(0)};
+#pragma unroll
+        for (int m = 0; m < MP; ++m) {
+            if (m < M) cfma(acc, rowb(A, m), colb(B, m));
+        }
+        return acc;
+    }
+    // Gauss-Jordan with partial pivoting over columns 0..npiv-1.  rhs is a per-row scalar replicated
+    // along the row.  Returns, per lane: perm[c] = row that pivoted column c, piv = pivot element of
+    // the lane's own row.
+    __device__ __forceinline__ void gauss_jordan(Cx<R>& A, Cx<R>& rhs, int npiv, bool used, int (&perm)[MP],
+                                                 Cx<R>& piv) const {
+#pragma unroll
+        for (int c = 0; c < MP; ++c) {
+            perm[c] = c;
+            if (c < npiv) {
+                const Cx<R> aic = rowb(A, c);
+                // arg max over rows of |A[i][c]|^2, row index packed into the low mantissa bits
+                float mag = used ? 0.f : (float)(aic.re * aic.re + aic.im * aic.im);
+                unsigned key = (__float_as_uint(mag) & ~(unsigned)(MP - 1)) | (unsigned)(MP - 1 - i);
+                key = used ? 0u : key;
+#pragma unroll
+                for (int off = MP; off < G; off <<= 1) {
+                    const unsigned o = (unsigned)__shfl_xor((int)key, off, G);
+                    key = o > key ? o : key;
+                }
+                const int p = MP - 1 - (int)(key & (unsigned)(MP - 1));
+                perm[c] = p;
+                const bool isp = (i == p);
+                const Cx<R> apc = colb(aic, p);
+                const Cx<R> apj = colb(A, p);
+                const Cx<R> bp = colb(rhs, p);
+                const Cx<R> fct = cmul(aic, cinv(apc));
+                if (isp) {
+                    used = true;
+                    piv = apc;
+                } else {
+                    cfms(A, fct, apj);
+                    cfms(rhs, fct, bp);
+                    if (j == c) A = {R(0), R(0)};
+                }
+            }
+        }
+    }
+};
+
+template <int MP, typename R>
+__global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
+    constexpr int G = MP * MP;
+    const int tid = threadIdx.x;
+    const Sq<MP, R> sq(tid % G);
+    const int i = sq.i, j = sq.j;
+    const int f_raw = blockIdx.x * (kBlock / G) + tid / G;
+    const bool fvalid = f_raw < a.F;
+    const int f = fvalid ? f_raw : a.F - 1;
+    const int M = a.M, K = a.K;
+    const int NA = M * M;
+    const bool in = i < M && j < M;
+    const Cx<R> zero = {R(0), R(0)};
+    const Cx<R> eye = {R(i == j ? 1 : 0), R(0)};
+
+    // B[i][j] = (W_hat^H)[i][j] = conj(W_hat[j][i]); identity outside M x M
+    Cx<R> B = eye;
+    if (in) {
+        const float2 v = a.What[((size_t)f * M + j) * M + i];
+        B = {R(v.x), R(-v.y)};
+    }
+    if (a.wscale != nullptr && i < K) {  // overiva.py:163 / :167
+        const R s = R(1) / R(a.wscale[i]);
+        B.re *= s;
+        B.im *= s;
+    }
+    int off = 0;
+    float sgn = 0.f;
+    if (in) herm_offsets(M, i, j, off, sgn);
+    Cx<R> C = zero;
+    if (in) {
+        const float* p = a.Cx + (size_t)f * NA + off;
+        C.re = R(p[0]);
+        if (sgn != 0.f) C.im = R(sgn * p[1]);
+    }
+    // Tm = rows of W^H Cx (rows >= K unused)
+    Cx<R> Tm = zero;
+    if (K < M) Tm = sq.matmul(B, C, M);
+
+    const int nsrc = a.init_only ? 0 : K;
+    const R invT = R(1) / R(a.T);
+    for (int s = 0; s <= nsrc; ++s) {
+        const bool solve = s < nsrc;
+        if (!solve && !a.init_only) break;
+        Cx<R> wi = zero, wj = zero;
+        if (solve) {
+            // V[i][j]: fixed-order fp64 sum of the frame-split partials
+            Cx<R> V = zero;
+            if (in) {
+                double sr = 0., si = 0.;
+                const float* p = a.Vpart + ((size_t)f * K + s) * NA + off;
+                const size_t stride = (size_t)a.F * K * NA;
+                const bool has_im = sgn != 0.f;
+#pragma unroll 4
+                for (int sp = 0; sp < a.nsplit; ++sp) {
+                    sr += (double)p[sp * stride];
+                    if (has_im) si += (double)p[sp * stride + 1];
+                }
+                V.re = R(sr) * invT;
+                V.im = R(si) * R(sgn) * invT;
+            }
+            Cx<R> A = sq.matmul(B, V, M);  // W_hat^H V
+            if (!in) A = eye;
+            Cx<R> rhs = {R(i == s ? 1 : 0), R(0)};
+            int perm[MP];
+            Cx<R> piv = {R(1), R(0)};
+            sq.gauss_jordan(A, rhs, MP, false, perm, piv);
+            const Cx<R> q = cmul(rhs, cinv(piv));  // = w[c] on the row that pivoted column c
+#pragma unroll
+            for (int c = 0; c < MP; ++c) {
+                const Cx<R> wc = sq.colb(q, perm[c]);
+                if (i == c) wi = wc;
+                if (j == c) wj = wc;
+            }
+            // d = w^H V w
+            const Cx<R> vw = cmul(V, wj);
+            const R d = sq.allsum(wi.re * vw.re + wi.im * vw.im);
+            const R sc = R(1) / sqrt(d);
+            wi.re *= sc;
+            wi.im *= sc;
+            wj.re *= sc;
+            wj.im *= sc;
+            if (i == s) B = {wj.re, -wj.im};
+        }
+        if (K < M) {
+            if (solve) {
+                // row s of W^H Cx = sum_m conj(w_m) Cx[m][:]
+                Cx<R> t = cmul(Cx<R>{wi.re, -wi.im}, C);
+                t.re = sq.colsum(t.re);
+                t.im = sq.colsum(t.im);
+                if (i == s) Tm = t;
+            }
+            Cx<R> Gm = (i < K) ? Tm : eye;
+            Cx<R> dummy = zero;
+            int perm[MP];
+            Cx<R> piv = {R(1), R(0)};
+            sq.gauss_jordan(Gm, dummy, K, i >= K, perm, piv);
+            const Cx<R> Jn = cmul(Gm, cinv(piv));  // on row perm[m]: J[m][j-K] for j >= K
+#pragma unroll
+            for (int m = 0; m < MP; ++m) {
+                if (m < K) {
+                    const Cx<R> row = sq.colb(Jn, perm[m]);   // lane (i, j): J[m][j-K]
+                    const Cx<R> tr = sq.transp(row);          // lane (i, j): J[m][i-K]
+                    // W_hat[m][i] = J[m][i-K]  ->  (W_hat^H)[i][m] = conj
+                    if (j == m && i >= K && i < M) B = {tr.re, -tr.im};
+                }
+            }
+        }
+    }
+    if (fvalid && in) a.What[((size_t)f * M + j) * M + i] = make_float2((float)B.re, (float)(-B.im));
+}
+
+template <int MP>
+hipError_t launch_sq(hipStream_t s, const UpdateArgs& a) {
+    const int bins_per_block = kBlock / (MP * MP);
+    dim3 grid((a.F + bins_per_block - 1) / bins_per_block);
+    if (a.use_double)
+        hipLaunchKernelGGL((update_sq_kernel<MP, double>), grid, dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL((update_sq_kernel<MP, float>), grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int SG>
 hipError_t launch_sg(hipStream_t s, const UpdateArgs& a) {
     const int bins_per_block = kBlock / SG;
@@ -309,6 +513,11 @@ hipError_t launch_sg(hipStream_t s, const UpdateArgs& a) {
 }  // namespace
 
 hipError_t launch_update(hipStream_t s, const UpdateArgs& a) {
+    if (a.layout == 0) {  // square layout: one lane per matrix element
+        if (a.M <= 2) return launch_sq<2>(s, a);
+        if (a.M <= 4) return launch_sq<4>(s, a);
+        if (a.M <= 8) return launch_sq<8>(s, a);
+    }
     if (a.M <= 2) return launch_sg<2>(s, a);
     if (a.M <= 4) return launch_sg<4>(s, a);
     if (a.M <= 8) return launch_sg<8>(s, a);

@@ -53,12 +53,10 @@ hipError_t launch_power(hipStream_t s, const float2* X, const float2* What, floa
 int pow_sources_per_pass(int M, int K);
 
 // Activation finalisation, overiva.py:152-173.
-//   parts [nparts][T][K] -> R (T,K) unnormalised r, Gsum [nblk][K] per-block sums of r
-hipError_t launch_rsum(hipStream_t s, const float* parts, int nparts, float* R, double* Gsum, int T, int K, int model,
-                       int F_total);
-//   R, Gsum -> Rinv (T,K) = 1/max(r/gamma, 1e-15), wscale (K) = gamma | sqrt(gamma)
-hipError_t launch_rfin(hipStream_t s, const float* R, const double* Gsum, float* Rinv, float* wscale, int T, int K,
-                       int model);
+//   parts [nparts][T][K] -> R (T,K) unnormalised r
+hipError_t launch_rsum(hipStream_t s, const float* parts, int nparts, float* R, int T, int K, int model, int F_total);
+//   R -> gamma = mean_t R; Rinv (T,K) = 1/max(r/gamma, 1e-15), wscale (K) = gamma | sqrt(gamma)
+hipError_t launch_rfin(hipStream_t s, const float* R, float* Rinv, float* wscale, int T, int K, int model);
 int rsum_blocks(int T);
 // sum of partial buffers: out[e] = sum_i parts[i][e]
 hipError_t launch_sum_parts(hipStream_t s, const float* parts, int nparts, float* out, long long n, float scale);
@@ -73,6 +71,7 @@ struct UpdateArgs {
     int T, F, M, K;
     int init_only;        // 1: only (re)compute J from W and Cx
     int use_double;       // per-bin algebra in fp64
+    int layout;           // 0: one lane per matrix element (M <= 8), 1: one lane per matrix row
 };
 hipError_t launch_update(hipStream_t s, const UpdateArgs& a);
 

@@ -53,7 +53,6 @@ struct oiva_plan {
     float* Plocal = nullptr;    // (T,K)
     float* R = nullptr;         // (T,K)
     float* Rinv = nullptr;      // (T,K)
-    double* Gsum = nullptr;     // [rsum_blocks][K]
     float* wscale = nullptr;    // (K)
     float* Spart = nullptr;     // [nsplit][F][K][3]
     float2* Y = nullptr;        // (T,F,K), allocated on first demix
@@ -128,11 +127,11 @@ int stage_power(oiva_plan* p) {
     return OIVA_OK;
 }
 int stage_rsum(oiva_plan* p, const float* parts, int nparts) {
-    HIP_TRY(launch_rsum(p->stream, parts, nparts, p->R, p->Gsum, p->T, p->K, p->model, p->F_total));
+    HIP_TRY(launch_rsum(p->stream, parts, nparts, p->R, p->T, p->K, p->model, p->F_total));
     return OIVA_OK;
 }
 int stage_rfin(oiva_plan* p) {
-    HIP_TRY(launch_rfin(p->stream, p->R, p->Gsum, p->Rinv, p->wscale, p->T, p->K, p->model));
+    HIP_TRY(launch_rfin(p->stream, p->R, p->Rinv, p->wscale, p->T, p->K, p->model));
     p->wscale_pending = true;
     return OIVA_OK;
 }
@@ -152,7 +151,8 @@ int stage_update(oiva_plan* p, bool init_only) {
     a.M = p->M;
     a.K = p->K;
     a.init_only = init_only ? 1 : 0;
-    a.use_double = p->use_double;
+    a.use_double = p->use_double & 1;
+    a.layout = (p->use_double >> 1) & 1;
     HIP_TRY(launch_update(p->stream, a));
     if (!init_only) p->wscale_pending = false;
     return OIVA_OK;
@@ -248,7 +248,6 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     alloc((void**)&p->Plocal, nTK * sizeof(float));
     alloc((void**)&p->R, nTK * sizeof(float));
     alloc((void**)&p->Rinv, nTK * sizeof(float));
-    alloc((void**)&p->Gsum, (size_t)rsum_blocks(T) * K * sizeof(double));
     alloc((void**)&p->wscale, (size_t)K * sizeof(float));
     alloc((void**)&p->scratch_c, (size_t)std::max(1, K) * nFMM * sizeof(float2));
     for (auto& ev : p->ev) {
@@ -273,7 +272,7 @@ int oiva_plan_destroy(oiva_plan* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     void* bufs[] = {p->X_owned, p->What, p->Cx,     p->Vpart, p->Ppart, p->Plocal, p->R,
-                    p->Rinv,    p->Gsum, p->wscale, p->Spart, p->Y,     p->scratch_c};
+                    p->Rinv,    p->wscale, p->Spart, p->Y,     p->scratch_c};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& ev : p->ev)
@@ -549,7 +548,7 @@ int oiva_plan_set_precision(oiva_plan* p, int fp64_update) {
     HIP_TRY(hipStreamSynchronize(p->stream));
     int rc = drop_graph(p);
     if (rc) return rc;
-    p->use_double = fp64_update ? 1 : 0;
+    p->use_double = fp64_update & 3;   // bit 0: fp64, bit 1 (test/tuning): row-per-lane layout
     return OIVA_OK;
 }
 

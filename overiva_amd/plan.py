@@ -137,8 +137,8 @@ class Plan:
     def use_graph(self, enable=True):
         _lib.check(self.lib.oiva_plan_use_graph(self.h, 1 if enable else 0))
 
-    def set_precision(self, fp64_update):
-        _lib.check(self.lib.oiva_plan_set_precision(self.h, 1 if fp64_update else 0))
+    def set_precision(self, fp64_update, row_layout=False):
+        _lib.check(self.lib.oiva_plan_set_precision(self.h, (1 if fp64_update else 0) | (2 if row_layout else 0)))
 
     # -- test-only stage access -----------------------------------------------------------------
     def t_set_rinv(self, rinv):

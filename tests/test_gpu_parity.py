@@ -24,6 +24,18 @@ def _amp(g, model, n_iter):
     return max(1.0, float(g.get(f"amp_{model}_{n_iter}", 1.0)))
 
 
+def _c64_floor(fn_ref64, ref128):
+    """distance of the reference algorithm's OWN complex64 arithmetic (oracle, reference-faithful
+    mode) from its complex128 result on the same input: no float32 implementation can be expected
+    to sit closer to the complex128 result than a small multiple of this."""
+    try:
+        with np.errstate(all="ignore"):
+            e = orc.rel_err(fn_ref64(), ref128)
+    except np.linalg.LinAlgError:
+        return np.inf
+    return e if np.isfinite(e) else np.inf
+
+
 @pytest.fixture(scope="module")
 def oa():
     import overiva_amd
@@ -93,9 +105,10 @@ def test_demix_power(oa, golden):
     assert orc.rel_err(pw, ref) < TOL_KERNEL
 
 
-@pytest.mark.parametrize("fp64", [False, True])
+@pytest.mark.parametrize("rows", [False, True], ids=["lane-per-element", "lane-per-row"])
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
 @pytest.mark.parametrize("model", ["laplace", "gauss"])
-def test_ip_update(oa, golden, model, fp64):
+def test_ip_update(oa, golden, model, fp64, rows):
     """weighted covariance + per-bin chain (IP1 solve, normalisation, J) from the reference's own
     traced state at overiva.py:181 (W_hat after gamma scaling, r_inv) -> W_hat after the epoch."""
     if f"im_{model}_e0_s0_V" not in golden:
@@ -106,7 +119,7 @@ def test_ip_update(oa, golden, model, fp64):
         rinv = golden[f"im_{model}_e{e}_s0_rinv"]
         W_in = golden[f"im_{model}_e{e}_s0_What"]
         with _plan(oa, X, K, model) as p:
-            p.set_precision(fp64)
+            p.set_precision(fp64, row_layout=rows)
             p.set_w(None)                  # marks the plan ready; state is overwritten next
             p.t_set_what(W_in)
             p.t_set_rinv(rinv)
@@ -157,7 +170,7 @@ def test_activation(oa, golden):
 @pytest.mark.parametrize("model", ["laplace", "gauss"])
 @pytest.mark.parametrize("n_iter", [0, 1, 2, 5, 20])
 @pytest.mark.parametrize("dt", ["c64", "c128"])
-def test_overiva_matches_reference(oa, golden, model, n_iter, dt, record_property):
+def test_overiva_matches_reference(oa, golden, model, n_iter, dt):
     if not _small(golden):
         pytest.skip("M > 8 needs the MFMA covariance path")
     if chaotic(golden, model, n_iter):
@@ -186,10 +199,16 @@ def test_proj_back_and_callback(oa, golden, model):
     if chaotic(golden, model, 12):
         pytest.skip("reference is ill-conditioned here (see conftest.chaotic)")
     X, K = golden["X"], int(golden["K"])
+    floor = _c64_floor(lambda: orc.overiva_faithful(X, n_src=K, n_iter=12, proj_back=True, model=model),
+                       golden[f"Ypb_c128_{model}_12"])
+    if floor > 1e-3:
+        pytest.skip(f"the reference's own complex64 run is {floor:.1e} away from its complex128 run here")
     got = []
     Y = oa.overiva(X.astype(np.complex128), n_src=K, n_iter=12, proj_back=True, model=model,
                    callback=lambda y: got.append(np.array(y)))
-    bound = TOL * _amp(golden, model, 12)
+    bound = max(TOL * _amp(golden, model, 12), 10 * floor)
+    print(f"\n[parity] {golden['_id']} {model} proj_back 12 its: Y err "
+          f"{orc.rel_err(Y, golden[f'Ypb_c128_{model}_12']):.2e} (reference c64 floor {floor:.1e}, bound {bound:.1e})")
     assert orc.rel_err(Y, golden[f"Ypb_c128_{model}_12"]) < bound
     assert len(got) == 2 and got[0].shape == Y.shape and got[0].dtype == np.complex128
     if model == "laplace":
@@ -203,10 +222,16 @@ def test_warm_start_default_nsrc_eig(oa, golden):
     X, K = golden["X"], int(golden["K"])
     X128 = X.astype(np.complex128)
     _, W = oa.overiva(X128, n_src=K, n_iter=3, proj_back=False, W0=golden["W0"], return_filters=True)
-    assert orc.rel_err(W, golden["W_w0_c128_laplace_3"]) < TOL * 3
+    floor = _c64_floor(lambda: orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=False, W0=golden["W0"],
+                                                    return_filters=True)[1], golden["W_w0_c128_laplace_3"])
+    assert orc.rel_err(W, golden["W_w0_c128_laplace_3"]) < max(TOL, 5 * floor)
     _, W = oa.overiva(X128, n_iter=2, proj_back=False, return_filters=True)
     assert W.shape == golden["W_det_c128_laplace_2"].shape
-    assert orc.rel_err(W, golden["W_det_c128_laplace_2"]) < TOL * 3
+    floor = _c64_floor(lambda: orc.overiva_faithful(X, n_iter=2, proj_back=False, return_filters=True)[1],
+                       golden["W_det_c128_laplace_2"])
+    print(f"\n[parity] {golden['_id']} determined 2 its: W err "
+          f"{orc.rel_err(W, golden['W_det_c128_laplace_2']):.2e} (reference c64 floor {floor:.1e})")
+    assert orc.rel_err(W, golden["W_det_c128_laplace_2"]) < max(TOL, 5 * floor)
     Y = oa.overiva(X128, n_src=K, n_iter=3, proj_back=False, init_eig=True)
     # eigenvector phase is LAPACK's choice: compare magnitudes
     assert orc.rel_err(np.abs(Y), np.abs(golden["Y_eig_c128_laplace_3"])) < 1e-4
