@@ -108,7 +108,7 @@ def run_single(args):
     cov_ms = stages["weighted_cov"] / args.steps
     bytes_cov = cov_algorithmic_bytes(T, F, M, K)
     achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "cov_kernel<8,2> (weighted spatial covariance, overiva.py:179)",
+    roofline = {"bound": "hbm", "kernel": "cov_dma_kernel<8,2> (weighted spatial covariance of both sources in one pass, overiva.py:179)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
                 "stage_ms_per_step": {k: v / args.steps for k, v in stages.items()},

@@ -116,17 +116,19 @@ int oiva_plan_sync(oiva_plan *p);
 /*
  * Measurement.  Runs n iterations bracketed by HIP events on the plan's stream and, when
  * per_kernel_ms is non-NULL, additionally brackets every kernel launch with events (eager
- * launches) and returns the summed time of each stage in per_kernel_ms[0..4]:
- * [0] demix+power pass, [1] r reduction, [2] r finalisation, [3] weighted-covariance pass,
- * [4] per-bin update.  total_ms = wall time of the n iterations on the device.  Synchronous.
+ * launches) and returns the summed time of each stage in per_kernel_ms[0..3]:
+ * [0] demix+power pass, [1] source activation (r, gamma, 1/r), [2] weighted-covariance pass,
+ * [3] per-bin update.  total_ms = wall time of the n iterations on the device.  Synchronous.
  */
 int oiva_plan_iterate_timed(oiva_plan *p, int n, float *total_ms, float *per_kernel_ms);
-#define OIVA_N_STAGES 5
+#define OIVA_N_STAGES 4
 
 /* Launch geometry of the weighted-covariance pass, for roofline accounting and tuning:
  * get/set the number of frame splits (0 = library default). */
 int oiva_plan_get_cov_splits(oiva_plan *p, int *nsplit);
 int oiva_plan_set_cov_splits(oiva_plan *p, int nsplit);
+/* same for the demix+power pass (0 = library default) */
+int oiva_plan_set_pow_splits(oiva_plan *p, int nsplit);
 /* Replay the iteration from a captured hipGraph instead of eager launches (default off). */
 int oiva_plan_use_graph(oiva_plan *p, int enable);
 /* Per-bin solve variant: bit 0 = arithmetic (0 float32 (default), 1 float64); bit 1 = lane layout
@@ -145,6 +147,9 @@ int oiva_test_run_update(oiva_plan *p);                       /* overiva.py:181-
 int oiva_test_get_what(oiva_plan *p, void *What_host /* (F,M,M) complex64 */);
 int oiva_test_set_what(oiva_plan *p, const void *What_host);
 int oiva_test_run_power(oiva_plan *p, float *p_host /* (T,K) summed over this plan's bins */);
+/* average duration of `reps` back-to-back launches of one stage (0 power, 1 activation, 2 covariance,
+ * 3 update) on the plan's current state, HIP events on the plan's stream */
+int oiva_test_time_stage(oiva_plan *p, int stage, int reps, float *avg_ms);
 
 #ifdef __cplusplus
 }

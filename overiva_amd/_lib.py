@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_PKG, "liboveriva_hip.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NUMERIC = 0, -1, -2, -3, -4
 MODEL_IDS = {"laplace": 0, "gauss": 1}
-N_STAGES = 5
-STAGE_NAMES = ("demix_power", "r_sum", "r_finalize", "weighted_cov", "ip_update")
+N_STAGES = 4
+STAGE_NAMES = ("demix_power", "activation", "weighted_cov", "ip_update")
 
 
 class HipLibraryMissing(ImportError):
@@ -50,6 +50,7 @@ SIGNATURES = {
     "oiva_plan_iterate_timed": [_vp, _i, _fp, _fp],
     "oiva_plan_get_cov_splits": [_vp, C.POINTER(_i)],
     "oiva_plan_set_cov_splits": [_vp, _i],
+    "oiva_plan_set_pow_splits": [_vp, _i],
     "oiva_plan_use_graph": [_vp, _i],
     "oiva_plan_set_precision": [_vp, _i],
     "oiva_test_set_rinv": [_vp, _vp],
@@ -60,6 +61,7 @@ SIGNATURES = {
     "oiva_test_get_what": [_vp, _vp],
     "oiva_test_set_what": [_vp, _vp],
     "oiva_test_run_power": [_vp, _vp],
+    "oiva_test_time_stage": [_vp, _i, _i, _fp],
 }
 
 

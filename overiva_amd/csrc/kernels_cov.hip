@@ -9,7 +9,10 @@
 // per frame instead of 4 M^2).  Per-lane partial sums cover ~T/(16*nsplit) frames; the 16 frame
 // phases of a block are combined through LDS (fixed order) and written as one packed partial per
 // (frame split, bin, source).  The per-bin update kernel adds the nsplit partials in fp64.
-#include "oiva_internal.h"
+#include <cstdint>
+#include <cstdlib>
+
+#include "oiva_device.h"
 
 namespace oiva {
 namespace {
@@ -86,58 +89,19 @@ __device__ __forceinline__ void accumulate(float (&acc)[KC][M * M], const float 
     }
 }
 
+constexpr int kCovUnroll = 2;            // frame steps in flight per wave
 constexpr int kChunk = 16;               // accumulators combined per LDS round
 constexpr int kLdsStride = kBlock + 1;   // +1: conflict-free transposed read
 
-template <int M, int KC, bool UNIT>
-__global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ X, const float* __restrict__ rinv,
-                                                     float* __restrict__ Vpart, int T, int F, int K, int tc) {
+// Combine the 16 frame phases of a workgroup (tid = q*16 + b) in rounds of kChunk accumulators through
+// LDS and store one packed partial per (frame split, bin, source):
+//   write lds[a][tid]; thread (bb = tid/16, aa = tid%16) sums lds[aa][qq*16 + bb] over qq (fixed order).
+template <int M, int KC>
+__device__ __forceinline__ void reduce_and_store(const float (&acc)[KC][M * M], float* lds, float* __restrict__ Vpart,
+                                                 int F, int K, int k0) {
     constexpr int NA = M * M;
     constexpr int NACC = NA * KC;
-    __shared__ float lds[kChunk * kLdsStride];
-
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int b = lane & (kBinsPerWave - 1);
-    const int q = wave * kPhasesPerWave + (lane >> 4);  // 0..15, == tid >> 4
-    const int f = blockIdx.x * kBinsPerWave + b;
-    const int fc = f < F ? f : F - 1;
-    const int k0 = blockIdx.z * KC;
-    const int t_begin = blockIdx.y * tc;
-    const int t_end = min(T, t_begin + tc);
-    const int nsteps = (t_end - t_begin + 15) >> 4;
-
-    float acc[KC][NA];
-#pragma unroll
-    for (int kk = 0; kk < KC; ++kk)
-#pragma unroll
-        for (int a = 0; a < NA; ++a) acc[kk][a] = 0.f;
-
-    const size_t frame_stride = (size_t)F * M;
-    const float2* px = X + ((size_t)(t_begin + q) * F + fc) * M;
-
-    for (int i = 0; i < nsteps; ++i) {
-        const int t = t_begin + q + 16 * i;
-        const bool live = t < t_end;
-        float xr[M], xi[M], w[KC];
-        // frames past the end are clamped (address stays legal) and weighted by 0
-        load_x<M>(live ? px : X + ((size_t)(T - 1) * F + fc) * M, xr, xi);
-#pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {
-            if constexpr (UNIT) {
-                w[kk] = live ? 1.f : 0.f;
-            } else {
-                const int k = k0 + kk;
-                w[kk] = (live && k < K) ? rinv[(size_t)t * K + k] : 0.f;
-            }
-        }
-        accumulate<M, KC, UNIT>(acc, xr, xi, w);
-        px += 16 * frame_stride;
-    }
-
-    // Combine the 16 frame phases (tid = q*16 + b) in rounds of kChunk accumulators through LDS:
-    //   write lds[a][tid]; thread (bb = tid/16, aa = tid%16) sums lds[aa][qq*16 + bb] over qq.
     const int bb = tid >> 4, aa = tid & 15;
     const int fo = blockIdx.x * kBinsPerWave + bb;
     float* out = Vpart + (((size_t)blockIdx.y * F + fo) * K + k0) * NA;
@@ -158,34 +122,294 @@ __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ 
     }
 }
 
-template <int M, int KC>
-hipError_t launch_one(hipStream_t s, const float2* X, const float* rinv, float* Vpart, int T, int F, int K,
-                      const CovGeom& g) {
-    dim3 grid(g.nbg, g.nsplit, (K + KC - 1) / KC);
-    if (rinv == nullptr) {
-        if constexpr (KC == 1) {
-            hipLaunchKernelGGL((cov_kernel<M, 1, true>), grid, dim3(kBlock), 0, s, X, rinv, Vpart, T, F, K, g.tc);
-        } else {
-            return hipErrorInvalidValue;
+template <int M, int KC, bool UNIT>
+__global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ X, const float* __restrict__ R,
+                                                     float* __restrict__ wscale, int model, int raw,
+                                                     float* __restrict__ Vpart, int T, int F, int K, int tc) {
+    constexpr int NA = M * M;
+    constexpr int NACC = NA * KC;
+    __shared__ float lds[kChunk * kLdsStride];
+    __shared__ double gscratch[kWaves];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = lane & (kBinsPerWave - 1);
+    const int q = wave * kPhasesPerWave + (lane >> 4);  // 0..15, == tid >> 4
+    const int f = blockIdx.x * kBinsPerWave + b;
+    const int fc = f < F ? f : F - 1;
+    const int k0 = blockIdx.z * KC;
+    const int t_begin = blockIdx.y * tc;
+    const int t_end = min(T, t_begin + tc);
+    const int nsteps = (t_end - t_begin + 15) >> 4;
+
+    // scale normalisation of the activations (overiva.py:158-159): 1/gamma for this pass's sources
+    float ginv[KC];
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) ginv[kk] = 1.f;
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const int k = k0 + kk;
+            const float gamma = block_gamma(R, T, K, k < K ? k : K - 1, gscratch);
+            if (!raw) ginv[kk] = 1.f / gamma;
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && k < K && wscale != nullptr)
+                wscale[k] = model == OIVA_MODEL_LAPLACE ? gamma : sqrtf(gamma);   // overiva.py:163 / :167
         }
-    } else {
-        hipLaunchKernelGGL((cov_kernel<M, KC, false>), grid, dim3(kBlock), 0, s, X, rinv, Vpart, T, F, K, g.tc);
     }
-    return hipGetLastError();
+
+    float acc[KC][NA];
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) acc[kk][a] = 0.f;
+
+    // kCovUnroll steps are loaded before any of them is consumed, so a wave keeps kCovUnroll * 64 * M * 8
+    // bytes in flight (at two waves per SIMD this, not occupancy, is what covers HBM latency).  Frames
+    // past the end of the split are clamped to a legal address and weighted by 0.
+    const size_t frame_stride = (size_t)F * M;
+    const float2* pbase = X + (size_t)fc * M;
+    for (int i = 0; i < nsteps; i += kCovUnroll) {
+        float xr[kCovUnroll][M], xi[kCovUnroll][M], rv[kCovUnroll][KC];
+#pragma unroll
+        for (int u = 0; u < kCovUnroll; ++u) {
+            const int t = t_begin + q + 16 * (i + u);
+            const int tcl = t < t_end ? t : T - 1;
+            if constexpr (!UNIT) {
+#pragma unroll
+                for (int kk = 0; kk < KC; ++kk) {
+                    const int k = k0 + kk;
+                    rv[u][kk] = R[(size_t)tcl * K + (k < K ? k : K - 1)];
+                }
+            }
+            load_x<M>(pbase + (size_t)tcl * frame_stride, xr[u], xi[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kCovUnroll; ++u) {
+            const int t = t_begin + q + 16 * (i + u);
+            const float mask = t < t_end ? 1.f : 0.f;
+            float w[KC];
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                if constexpr (UNIT)
+                    w[kk] = mask;
+                else
+                    w[kk] = activation_weight(rv[u][kk], ginv[kk]) * ((k0 + kk < K) ? mask : 0.f);
+            }
+            accumulate<M, KC, UNIT>(acc, xr[u], xi[u], w);
+        }
+    }
+
+    reduce_and_store<M, KC>(acc, lds, Vpart, F, K, k0);
 }
 
-template <int M>
-hipError_t launch_m(hipStream_t s, const float2* X, const float* rinv, float* Vpart, int T, int F, int K,
-                    const CovGeom& g) {
-    switch (g.kc) {
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant of the weighted pass (even M).  Same lane geometry and arithmetic as cov_kernel, but
+// X goes HBM -> LDS with global_load_lds (no staging registers) into a private 4-stage ring per wave:
+// three steps (3 * 64 lanes * M*8 bytes) stay in flight while the fourth is consumed, which is what a
+// kernel limited to two waves per SIMD by its 128 accumulators needs to cover HBM latency.  Each lane
+// reads back exactly the bytes it requested (piece j of its own M-vector lands at
+// stage_base + j*1024 + lane*16), so the ring needs no swizzle and no workgroup barrier; the only
+// ordering is the wave's own vmcnt.  The LDS reads and both counted waits sit in one asm block:
+// hipcc otherwise drains the whole DMA queue (vmcnt(0)) in front of any LDS read it can see.
+// The weights r[t,k] of the wave's four frame phases are wave-uniform and come through the scalar cache.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDmaStages = 4;
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+template <int PIECES>
+__device__ __forceinline__ void ring_read(unsigned addr, float4 (&v)[PIECES]);
+
+template <>
+__device__ __forceinline__ void ring_read<4>(unsigned addr, float4 (&v)[4]) {
+    asm volatile(
+        "s_waitcnt vmcnt(12)\n\t"
+        "ds_read_b128 %0, %4\n\t"
+        "ds_read_b128 %1, %4 offset:1024\n\t"
+        "ds_read_b128 %2, %4 offset:2048\n\t"
+        "ds_read_b128 %3, %4 offset:3072\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+        : "v"(addr)
+        : "memory");
+}
+template <>
+__device__ __forceinline__ void ring_read<2>(unsigned addr, float4 (&v)[2]) {
+    asm volatile(
+        "s_waitcnt vmcnt(6)\n\t"
+        "ds_read_b128 %0, %2\n\t"
+        "ds_read_b128 %1, %2 offset:1024\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1])
+        : "v"(addr)
+        : "memory");
+}
+
+template <int M, int KC>
+__global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __restrict__ X, const float* __restrict__ R,
+                                                            float* __restrict__ wscale, int model, int raw,
+                                                            float* __restrict__ Vpart, int T, int F, int K, int tc) {
+    constexpr int NA = M * M;
+    constexpr int PIECES = M / 2;                       // 16-byte pieces of one M-vector
+    constexpr int STAGE = PIECES * 64;                  // float4 per stage per wave
+    static_assert(M % 2 == 0 && (PIECES == 2 || PIECES == 4), "LDS-DMA path: M in {4, 8}");
+    __shared__ float4 ring[kWaves * kDmaStages * STAGE];
+    __shared__ double gscratch[kWaves];
+    static_assert(sizeof(float4) * kWaves * kDmaStages * STAGE >= sizeof(float) * kChunk * kLdsStride,
+                  "reduction scratch aliases the ring");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = lane & (kBinsPerWave - 1);
+    const int ql = lane >> 4;                           // phase inside the wave
+    const int q = wave * kPhasesPerWave + ql;           // 0..15
+    const int f = blockIdx.x * kBinsPerWave + b;
+    const int fc = f < F ? f : F - 1;
+    const int k0 = blockIdx.z * KC;
+    const int t_begin = blockIdx.y * tc;
+    const int t_end = min(T, t_begin + tc);
+    const int nsteps = (t_end - t_begin + 15) >> 4;
+
+    float acc[KC][NA];
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) acc[kk][a] = 0.f;
+
+    float ginv[KC];
+    float4* wring = ring + wave * kDmaStages * STAGE;                       // wave-uniform
+    const unsigned rd_base = (unsigned)(uintptr_t)(wring) + lane * 16;      // LDS byte address of this lane's slot
+    const size_t frame_stride = (size_t)F * M;
+    const float2* pbase = X + (size_t)fc * M;
+
+    // issue the M/2 DMA requests of step i into stage s; steps past the end re-request the last frame
+    // (legal address, never consumed) so that every step adds the same count to vmcnt
+    auto issue = [&](int i, int s) {
+        const int t = t_begin + q + 16 * i;
+        const int tcl = (i < nsteps && t < t_end) ? t : T - 1;
+        const float2* src = pbase + (size_t)tcl * frame_stride;
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j)
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(src + 2 * j), (lvoid_t*)(wring + s * STAGE + j * 64), 16, 0, 0);
+    };
+    // lane masks selecting the lane's phase among the wave's four frames (arithmetic select: a ?: chain on
+    // a lane-varying condition gets compiled into branches with the scalar loads inside them)
+    const float m0 = ql == 0 ? 1.f : 0.f, m1 = ql == 1 ? 1.f : 0.f, m2 = ql == 2 ? 1.f : 0.f, m3 = ql == 3 ? 1.f : 0.f;
+    auto consume = [&](int i, int s) {
+        // weights of the wave's four consecutive frames: uniform addresses -> scalar loads.  R is
+        // allocated with kPhasesPerWave zeroed rows of padding, so reading past frame T-1 is legal.
+        const int tw = t_begin + wave * kPhasesPerWave + 16 * i;
+        const float* rp = R + (size_t)tw * K;
+        float w[KC];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const int k = k0 + kk < K ? k0 + kk : K - 1;
+            const float r = m0 * rp[k] + m1 * rp[K + k] + m2 * rp[2 * K + k] + m3 * rp[3 * K + k];
+            const float live = (tw + ql < t_end && k0 + kk < K) ? 1.f : 0.f;
+            w[kk] = activation_weight(r, ginv[kk]) * live;
+        }
+        float4 v[PIECES];
+        ring_read<PIECES>(rd_base + s * STAGE * 16, v);
+        float xr[M], xi[M];
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            xr[2 * j] = v[j].x;
+            xi[2 * j] = v[j].y;
+            xr[2 * j + 1] = v[j].z;
+            xi[2 * j + 1] = v[j].w;
+        }
+        if (raw & 2) {   // tuning ablation: memory path only, a token amount of arithmetic
+#pragma unroll
+            for (int c = 0; c < M; ++c) acc[0][c] = fmaf(w[0], xr[c] + xi[c], acc[0][c]);
+        } else {
+            accumulate<M, KC, false>(acc, xr, xi, w);
+        }
+    };
+
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
+    // scale normalisation of the activations (overiva.py:158-159), computed while the first three steps
+    // are on their way from HBM
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+        const int k = k0 + kk;
+        const float gamma = block_gamma(R, T, K, k < K ? k : K - 1, gscratch);
+        ginv[kk] = (raw & 1) ? 1.f : 1.f / gamma;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && k < K && wscale != nullptr)
+            wscale[k] = model == OIVA_MODEL_LAPLACE ? gamma : sqrtf(gamma);   // overiva.py:163 / :167
+    }
+
+    int i = 0;
+    for (; i + 4 <= nsteps; i += 4) {       // stage indices are compile-time constants in the unrolled body
+        issue(i + 3, 3); consume(i, 0);
+        issue(i + 4, 0); consume(i + 1, 1);
+        issue(i + 5, 1); consume(i + 2, 2);
+        issue(i + 6, 2); consume(i + 3, 3);
+    }
+    // 0..3 remaining steps; the stage sequence restarts at 0 because i is a multiple of 4
+    if (i < nsteps) { issue(i + 3, 3); consume(i, 0); }
+    if (i + 1 < nsteps) { issue(i + 4, 0); consume(i + 1, 1); }
+    if (i + 2 < nsteps) { issue(i + 5, 1); consume(i + 2, 2); }
+    // drain the DMA queue before the ring is reused as reduction scratch
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    reduce_and_store<M, KC>(acc, reinterpret_cast<float*>(ring), Vpart, F, K, k0);
+}
+
+using CovKernel = void (*)(const float2*, const float*, float*, int, int, float*, int, int, int, int);
+
+// OIVA_COV_DMA=0 selects the register-staged kernel (A/B tuning); default: LDS-DMA ring where available
+inline bool use_dma_path() {
+    static const bool on = !(getenv("OIVA_COV_DMA") && atoi(getenv("OIVA_COV_DMA")) == 0);
+    return on;
+}
+
+// (M, KC, unit weights) -> kernel instantiation, handed to fn together with its KC
+template <int M, typename Fn>
+hipError_t dispatch_kc(int kc, bool unit, Fn&& fn) {
+    if (unit) return kc == 1 ? fn((CovKernel)cov_kernel<M, 1, true>, 1) : hipErrorInvalidValue;
+    if constexpr (M == 4 || M == 8) {
+        if (use_dma_path()) {
+            switch (kc) {
+                case 1:
+                    return fn((CovKernel)cov_dma_kernel<M, 1>, 1);
+                case 2:
+                    if constexpr (M * M * 2 <= 144) return fn((CovKernel)cov_dma_kernel<M, 2>, 2);
+                    break;
+                case 4:
+                    if constexpr (M * M * 4 <= 144) return fn((CovKernel)cov_dma_kernel<M, 4>, 4);
+                    break;
+            }
+            return hipErrorInvalidValue;
+        }
+    }
+    switch (kc) {
         case 1:
-            return launch_one<M, 1>(s, X, rinv, Vpart, T, F, K, g);
+            return fn((CovKernel)cov_kernel<M, 1, false>, 1);
         case 2:
-            if constexpr (M * M * 2 <= 144) return launch_one<M, 2>(s, X, rinv, Vpart, T, F, K, g);
+            if constexpr (M * M * 2 <= 144) return fn((CovKernel)cov_kernel<M, 2, false>, 2);
             break;
         case 4:
-            if constexpr (M * M * 4 <= 144) return launch_one<M, 4>(s, X, rinv, Vpart, T, F, K, g);
+            if constexpr (M * M * 4 <= 144) return fn((CovKernel)cov_kernel<M, 4, false>, 4);
             break;
+    }
+    return hipErrorInvalidValue;
+}
+
+template <typename Fn>
+hipError_t dispatch_cov(int M, int kc, bool unit, Fn&& fn) {
+    switch (M) {
+        case 1: return dispatch_kc<1>(kc, unit, fn);
+        case 2: return dispatch_kc<2>(kc, unit, fn);
+        case 3: return dispatch_kc<3>(kc, unit, fn);
+        case 4: return dispatch_kc<4>(kc, unit, fn);
+        case 5: return dispatch_kc<5>(kc, unit, fn);
+        case 6: return dispatch_kc<6>(kc, unit, fn);
+        case 7: return dispatch_kc<7>(kc, unit, fn);
+        case 8: return dispatch_kc<8>(kc, unit, fn);
     }
     return hipErrorInvalidValue;
 }
@@ -202,19 +426,20 @@ int cov_sources_per_pass(int M, int K) {
     return kc;
 }
 
-hipError_t launch_cov(hipStream_t s, const float2* X, const float* rinv, float* Vpart, int T, int F, int M, int K,
-                      const CovGeom& g) {
-    switch (M) {
-        case 1: return launch_m<1>(s, X, rinv, Vpart, T, F, K, g);
-        case 2: return launch_m<2>(s, X, rinv, Vpart, T, F, K, g);
-        case 3: return launch_m<3>(s, X, rinv, Vpart, T, F, K, g);
-        case 4: return launch_m<4>(s, X, rinv, Vpart, T, F, K, g);
-        case 5: return launch_m<5>(s, X, rinv, Vpart, T, F, K, g);
-        case 6: return launch_m<6>(s, X, rinv, Vpart, T, F, K, g);
-        case 7: return launch_m<7>(s, X, rinv, Vpart, T, F, K, g);
-        case 8: return launch_m<8>(s, X, rinv, Vpart, T, F, K, g);
-    }
-    return hipErrorInvalidValue;
+hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* wscale, int model, int raw, float* Vpart,
+                      int T, int F, int M, int K, const CovGeom& g) {
+    return dispatch_cov(M, g.kc, R == nullptr, [&](CovKernel kern, int KC) {
+        dim3 grid(g.nbg, g.nsplit, (K + KC - 1) / KC);
+        kern<<<grid, dim3(kBlock), 0, s>>>(X, R, wscale, model, raw, Vpart, T, F, K, g.tc);
+        return hipGetLastError();
+    });
+}
+
+// workgroups of this instantiation that one CU holds at once (registers / LDS limited)
+hipError_t cov_blocks_per_cu(int M, int kc, int* n) {
+    return dispatch_cov(M, kc, false, [&](CovKernel kern, int) {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, kern, kBlock, 0);
+    });
 }
 
 }  // namespace oiva

@@ -4,6 +4,8 @@
 //           (Y itself is never stored inside the loop: the reference's Y /= gamma at :162/:166 is dead)
 //   stats : per-bin sums for projection back          reference overiva.py:197-198 (pyroomacoustics formula)
 //   write : Y[t,f,k] = w_{f,k}^H x_{t,f} (* conj z)   reference overiva.py:192-199
+#include <cstdlib>
+
 #include "oiva_internal.h"
 
 namespace oiva {
@@ -63,8 +65,6 @@ __device__ __forceinline__ void demix_one(const float (&wr)[M], const float (&wi
     yi = ai;
 }
 
-__device__ __forceinline__ float dpp_add(float v, const int ctrl_tag);
-
 // sum over the 16 lanes of a DPP row (= the 16 bins of one frame phase); every lane gets the total
 __device__ __forceinline__ float row16_sum(float v) {
     int x;
@@ -82,6 +82,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 // ---------------------------------------------------------------------------------------------
 // power: block = 4 waves x 16 bins = 64 bins, 4 frame phases per wave, frames [t_begin, t_begin+tcp)
 // ---------------------------------------------------------------------------------------------
+constexpr int kPowUnroll = 4;
+
 template <int M, int KP>
 __global__ __launch_bounds__(kBlock) void power_kernel(const float2* __restrict__ X, const float2* __restrict__ What,
                                                        float* __restrict__ Ppart, int T, int F, int K, int tcp) {
@@ -103,24 +105,33 @@ __global__ __launch_bounds__(kBlock) void power_kernel(const float2* __restrict_
     float wr[KP][M], wi[KP][M];
     load_wconj<M, KP>(What, fc, k0, K, wr, wi);
 
+    // kPowUnroll steps are loaded before any of them is consumed: a wave keeps kPowUnroll * 64 * M * 8
+    // bytes in flight, which is what hides HBM latency here (more resident waves only thrash the L1,
+    // because a lane's M*8 bytes arrive through M/2 separate dwordx4 requests to the same lines).
     const size_t frame_stride = (size_t)F * M;
-    const float2* px = X + ((size_t)(t_begin + q) * F + fc) * M;
-    const float2* plast = X + ((size_t)(T - 1) * F + fc) * M;
-    for (int i = 0; i < nsteps; ++i) {
-        const int tl = 4 * i + q;
-        const bool live = tl < len;
-        float xr[M], xi[M];
-        load_x<M>(live ? px : plast, xr, xi);
+    const float2* pbase = X + (size_t)fc * M;
+    for (int i = 0; i < nsteps; i += kPowUnroll) {
+        float xr[kPowUnroll][M], xi[kPowUnroll][M];
 #pragma unroll
-        for (int kk = 0; kk < KP; ++kk) {
-            float yr, yi;
-            demix_one<M>(wr[kk], wi[kk], xr, xi, yr, yi);
-            float pw = fmaf(yr, yr, yi * yi);
-            pw = fvalid ? pw : 0.f;
-            pw = row16_sum(pw);
-            if (b == 0 && live) sp[(wave * tcp + tl) * KP + kk] = pw;
+        for (int u = 0; u < kPowUnroll; ++u) {
+            const int tl = 4 * (i + u) + q;
+            const int t = tl < len ? t_begin + tl : T - 1;      // clamped: legal address, result unused
+            load_x<M>(pbase + (size_t)t * frame_stride, xr[u], xi[u]);
         }
-        px += 4 * frame_stride;
+#pragma unroll
+        for (int u = 0; u < kPowUnroll; ++u) {
+            const int tl = 4 * (i + u) + q;
+            const bool live = tl < len;
+#pragma unroll
+            for (int kk = 0; kk < KP; ++kk) {
+                float yr, yi;
+                demix_one<M>(wr[kk], wi[kk], xr[u], xi[u], yr, yi);
+                float pw = fmaf(yr, yr, yi * yi);
+                pw = fvalid ? pw : 0.f;
+                pw = row16_sum(pw);
+                if (b == 0 && live) sp[(wave * tcp + tl) * KP + kk] = pw;
+            }
+        }
     }
     __syncthreads();
     for (int e = tid; e < len * KP; e += kBlock) {
@@ -258,7 +269,9 @@ template <int M, int KP>
 hipError_t launch_power_one(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int K,
                             const PowGeom& g) {
     dim3 grid(g.nb, g.nsplit, (K + KP - 1) / KP);
-    const size_t shmem = (size_t)kWaves * g.tcp * KP * sizeof(float);
+    size_t shmem = (size_t)kWaves * g.tcp * KP * sizeof(float);
+    static const size_t pad = getenv("OIVA_POW_LDS_PAD") ? (size_t)atol(getenv("OIVA_POW_LDS_PAD")) : 0;  // tuning only
+    shmem += pad;
     hipLaunchKernelGGL((power_kernel<M, KP>), grid, dim3(kBlock), shmem, s, X, What, Ppart, T, F, K, g.tcp);
     return hipGetLastError();
 }
@@ -307,6 +320,19 @@ int pow_sources_per_pass(int M, int K) {
     if (K >= 3 && M <= 8) return 4;
     if (K >= 2) return 2;
     return 1;
+}
+
+hipError_t pow_blocks_per_cu(int M, int kp, int tcp, int* n) {
+    const size_t shmem = (size_t)kWaves * tcp * kp * sizeof(float);
+#define CALL(MM)                                                                                                   \
+    if (kp == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, power_kernel<MM, 1>, kBlock, shmem);       \
+    if (kp == 2) return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, power_kernel<MM, 2>, kBlock, shmem);       \
+    if constexpr (MM <= 8) {                                                                                       \
+        if (kp == 4) return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, power_kernel<MM, 4>, kBlock, shmem);   \
+    }
+    OIVA_DISPATCH_M(CALL)
+#undef CALL
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_power(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K,

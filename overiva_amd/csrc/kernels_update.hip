@@ -38,8 +38,8 @@ __device__ __forceinline__ void cfms(Cx<R>& acc, Cx<R> a, Cx<R> b) {  // acc -= 
 }
 template <typename R>
 __device__ __forceinline__ Cx<R> cinv(Cx<R> a) {
-    const R d = a.re * a.re + a.im * a.im;
-    return {a.re / d, -a.im / d};
+    const R d = R(1) / (a.re * a.re + a.im * a.im);
+    return {a.re * d, -a.im * d};
 }
 template <int SG, typename R>
 __device__ __forceinline__ R gshfl(R v, int src) {
@@ -301,6 +301,53 @@ __global__ __launch_bounds__(kBlock) void update_kernel(UpdateArgs a) {
 // 2048 independent waves and each elimination step is O(1) arithmetic per lane: the sequential chain
 // per source is ~MP pivots x (a handful of cross-lane moves + one complex divide + one complex FMA).
 // ---------------------------------------------------------------------------------------------
+// ---- register-level lane exchanges (no LDS crossbar): DPP within 16-lane rows, v_permlane{16,32}_swap
+//      across rows.  Values wider than 32 bits go through them one dword at a time. ----
+template <int CTRL>
+__device__ __forceinline__ int dpp32(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) { return __int_as_float(dpp32<CTRL>(__float_as_int(v))); }
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp(unsigned v) { return (unsigned)dpp32<CTRL>((int)v); }
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+    return __hiloint2double(dpp32<CTRL>(__double2hiint(v)), dpp32<CTRL>(__double2loint(v)));
+}
+constexpr int kDppXor1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;   // quad_perm [2,3,0,1]
+constexpr int kDppRor4 = 0x124;  // row_ror:4
+constexpr int kDppRor8 = 0x128;  // row_ror:8
+// a + b where b is the value of the lane 16 (32) lanes away: the swap of a register with itself
+// leaves {own row pair member, other row pair member} in the two results
+__device__ __forceinline__ float swapsum16(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swapsum32(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ double swapsum16(double v) {
+    auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double swapsum32(double v) {
+    auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ unsigned swapmax16(unsigned v) {
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return r[0] > r[1] ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned swapmax32(unsigned v) {
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return r[0] > r[1] ? r[0] : r[1];
+}
+
 template <int MP, typename R>
 struct Sq {
     static constexpr int G = MP * MP;
@@ -316,15 +363,47 @@ struct Sq {
     __device__ __forceinline__ Cx<R> transp(Cx<R> v) const {
         return {__shfl(v.re, j * MP + i, G), __shfl(v.im, j * MP + i, G)};
     }
-    // sum over the rows of a column (every lane of the column gets it)
+    // sum over the rows of a column (every lane of the column gets it).  Lane = i*MP + j, so the rows
+    // of a column are MP lanes apart: rotations inside a 16-lane DPP row, then row swaps.
     __device__ __forceinline__ R colsum(R v) const {
-#pragma unroll
-        for (int off = MP; off < G; off <<= 1) v += __shfl_xor(v, off, G);
+        if constexpr (MP == 2) {
+            v += dpp<kDppXor2>(v);
+        } else if constexpr (MP == 4) {
+            v += dpp<kDppRor4>(v);
+            v += dpp<kDppRor8>(v);
+        } else {
+            v += dpp<kDppRor8>(v);
+            v = swapsum16(v);
+            v = swapsum32(v);
+        }
         return v;
     }
+    __device__ __forceinline__ unsigned colmax(unsigned v) const {
+        unsigned o;
+        if constexpr (MP == 2) {
+            o = dpp<kDppXor2>(v); v = o > v ? o : v;
+        } else if constexpr (MP == 4) {
+            o = dpp<kDppRor4>(v); v = o > v ? o : v;
+            o = dpp<kDppRor8>(v); v = o > v ? o : v;
+        } else {
+            o = dpp<kDppRor8>(v); v = o > v ? o : v;
+            v = swapmax16(v);
+            v = swapmax32(v);
+        }
+        return v;
+    }
+    // sum over all MP*MP lanes of the group
     __device__ __forceinline__ R allsum(R v) const {
-#pragma unroll
-        for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, G);
+        v += dpp<kDppXor1>(v);
+        v += dpp<kDppXor2>(v);
+        if constexpr (MP >= 4) {
+            v += dpp<kDppRor4>(v);   // quads are uniform now: two rotations add the four quads of a row
+            v += dpp<kDppRor8>(v);
+        }
+        if constexpr (MP == 8) {
+            v = swapsum16(v);
+            v = swapsum32(v);
+        }
         return v;
     }
     // C = A * B for matrices distributed one element per lane; only the first M rows/cols of the
@@ -351,11 +430,7 @@ struct Sq {
                 float mag = used ? 0.f : (float)(aic.re * aic.re + aic.im * aic.im);
                 unsigned key = (__float_as_uint(mag) & ~(unsigned)(MP - 1)) | (unsigned)(MP - 1 - i);
                 key = used ? 0u : key;
-#pragma unroll
-                for (int off = MP; off < G; off <<= 1) {
-                    const unsigned o = (unsigned)__shfl_xor((int)key, off, G);
-                    key = o > key ? o : key;
-                }
+                key = colmax(key);
                 const int p = MP - 1 - (int)(key & (unsigned)(MP - 1));
                 perm[c] = p;
                 const bool isp = (i == p);
@@ -415,34 +490,43 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
     Cx<R> Tm = zero;
     if (K < M) Tm = sq.matmul(B, C, M);
 
-    const int nsrc = a.init_only ? 0 : K;
+    int nsrc = a.init_only ? 0 : K;
+    if (a.dbg & 1) nsrc = 0;          // ablation: loads/stores only
     const R invT = R(1) / R(a.T);
+    // V_s[i][j] = (1/T) * fixed-order fp64 sum of the frame-split partials (reduction tail of overiva.py:179)
+    auto load_v = [&](int s) {
+        Cx<R> V = zero;
+        if (in) {
+            double sr = 0., si = 0.;
+            const float* p = a.Vpart + ((size_t)f * K + s) * NA + off;
+            const size_t stride = (size_t)a.F * K * NA;
+            const bool has_im = sgn != 0.f;
+#pragma unroll 4
+            for (int sp = 0; sp < a.nsplit; ++sp) {
+                sr += (double)p[sp * stride];
+                if (has_im) si += (double)p[sp * stride + 1];
+            }
+            V.re = R(sr) * invT;
+            V.im = R(si) * R(sgn) * invT;
+        }
+        return V;
+    };
+    Cx<R> Vnext = zero;
+    if (nsrc > 0) Vnext = load_v(0);
     for (int s = 0; s <= nsrc; ++s) {
         const bool solve = s < nsrc;
         if (!solve && !a.init_only) break;
         Cx<R> wi = zero, wj = zero;
         if (solve) {
-            // V[i][j]: fixed-order fp64 sum of the frame-split partials
-            Cx<R> V = zero;
-            if (in) {
-                double sr = 0., si = 0.;
-                const float* p = a.Vpart + ((size_t)f * K + s) * NA + off;
-                const size_t stride = (size_t)a.F * K * NA;
-                const bool has_im = sgn != 0.f;
-#pragma unroll 4
-                for (int sp = 0; sp < a.nsplit; ++sp) {
-                    sr += (double)p[sp * stride];
-                    if (has_im) si += (double)p[sp * stride + 1];
-                }
-                V.re = R(sr) * invT;
-                V.im = R(si) * R(sgn) * invT;
-            }
+            // V_s was fetched while the previous source was being solved; start the fetch of V_{s+1}
+            const Cx<R> V = Vnext;
+            if (s + 1 < nsrc) Vnext = load_v(s + 1);
             Cx<R> A = sq.matmul(B, V, M);  // W_hat^H V
             if (!in) A = eye;
             Cx<R> rhs = {R(i == s ? 1 : 0), R(0)};
             int perm[MP];
             Cx<R> piv = {R(1), R(0)};
-            sq.gauss_jordan(A, rhs, MP, false, perm, piv);
+            sq.gauss_jordan(A, rhs, (a.dbg & 2) ? 1 : MP, false, perm, piv);
             const Cx<R> q = cmul(rhs, cinv(piv));  // = w[c] on the row that pivoted column c
 #pragma unroll
             for (int c = 0; c < MP; ++c) {
@@ -460,7 +544,7 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
             wj.im *= sc;
             if (i == s) B = {wj.re, -wj.im};
         }
-        if (K < M) {
+        if (K < M && !(a.dbg & 4)) {
             if (solve) {
                 // row s of W^H Cx = sum_m conj(w_m) Cx[m][:]
                 Cx<R> t = cmul(Cx<R>{wi.re, -wi.im}, C);

@@ -1,0 +1,51 @@
+// Device-side helpers shared by several kernels.
+#pragma once
+#include "oiva_internal.h"
+
+namespace oiva {
+
+constexpr float kEpsR = 1e-15f;  // reference overiva.py:170
+
+// block-wide sum of one double per thread, fixed order (wave shuffle tree, then the waves in order);
+// every thread of the block must call it; scratch holds kWaves doubles
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+    __syncthreads();
+    double s = 0.;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s += scratch[w];
+    return s;
+}
+
+// gamma_k = mean_t R[t,k]  (reference overiva.py:158), computed by a whole workgroup in a fixed order so
+// that every workgroup of every kernel obtains the same bits.  R is (T, K), a few KB, L2 resident.
+// Loads are issued 16 at a time so the cost is a couple of memory round trips, not T/256 of them.
+__device__ __forceinline__ float block_gamma(const float* __restrict__ R, int T, int K, int k, double* scratch) {
+    constexpr int kBatch = 16;
+    double s = 0.;
+    for (int t0 = threadIdx.x; t0 < T; t0 += kBlock * kBatch) {
+        float v[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int t = t0 + u * kBlock;
+            v[u] = R[(size_t)(t < T ? t : T - 1) * K + k];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) s += (t0 + u * kBlock < T) ? (double)v[u] : 0.;
+    }
+    s = block_sum(s, scratch);
+    return (float)(s / (double)T);
+}
+
+// 1 / max(r / gamma, eps)   (reference overiva.py:159, :170-173) with ginv = 1 / gamma
+__device__ __forceinline__ float activation_weight(float r, float ginv) {
+    float rn = r * ginv;
+    rn = rn < kEpsR ? kEpsR : rn;   // a NaN stays NaN, like r[r < eps] = eps in the reference
+    return 1.f / rn;
+}
+
+}  // namespace oiva

@@ -39,11 +39,14 @@ constexpr int kPowMaxFrames = 512;
 
 // ---- launchers (one per kernel family; each .hip file owns its template instantiations) -------
 // Weighted covariance pass, overiva.py:179 (and :87 with unit weights).
-//   X (T,F,M) c64, rinv (T,K) f32 or nullptr for unit weights (then K must be 1)
+//   X (T,F,M) c64; R (T,K) f32 activations r (unnormalised) or nullptr for unit weights (then K must be 1)
+//   weights: w[t,k] = 1 / max(R[t,k] / gamma_k, eps), gamma_k = mean_t R (overiva.py:158-173); with raw != 0
+//   gamma is taken as 1.  wscale (K): out, gamma (laplace) | sqrt(gamma) (gauss), written by one workgroup.
 //   Vpart [nsplit][F][K][M*M] packed partial sums (NOT divided by T)
-hipError_t launch_cov(hipStream_t s, const float2* X, const float* rinv, float* Vpart, int T, int F, int M,
-                      int K, const CovGeom& g);
+hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* wscale, int model, int raw, float* Vpart,
+                      int T, int F, int M, int K, const CovGeom& g);
 int cov_sources_per_pass(int M, int K);
+hipError_t cov_blocks_per_cu(int M, int kc, int* n);
 bool cov_supported(int M);
 
 // Demix + source power, overiva.py:140 + the norms at :153/:155.
@@ -51,13 +54,11 @@ bool cov_supported(int M);
 hipError_t launch_power(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M,
                         int K, const PowGeom& g);
 int pow_sources_per_pass(int M, int K);
+hipError_t pow_blocks_per_cu(int M, int kp, int tcp, int* n);
 
-// Activation finalisation, overiva.py:152-173.
-//   parts [nparts][T][K] -> R (T,K) unnormalised r
-hipError_t launch_rsum(hipStream_t s, const float* parts, int nparts, float* R, int T, int K, int model, int F_total);
-//   R -> gamma = mean_t R; Rinv (T,K) = 1/max(r/gamma, 1e-15), wscale (K) = gamma | sqrt(gamma)
-hipError_t launch_rfin(hipStream_t s, const float* R, float* Rinv, float* wscale, int T, int K, int model);
-int rsum_blocks(int T);
+// Source activation, overiva.py:152-155: parts [nparts][T][K] -> R (T,K) = 2 sqrt(p) | p / F_total.
+hipError_t launch_activation(hipStream_t s, const float* parts, int nparts, float* R, int T, int K, int model,
+                             int F_total);
 // sum of partial buffers: out[e] = sum_i parts[i][e]
 hipError_t launch_sum_parts(hipStream_t s, const float* parts, int nparts, float* out, long long n, float scale);
 
@@ -72,6 +73,7 @@ struct UpdateArgs {
     int init_only;        // 1: only (re)compute J from W and Cx
     int use_double;       // per-bin algebra in fp64
     int layout;           // 0: one lane per matrix element (M <= 8), 1: one lane per matrix row
+    int dbg;              // ablation mask, tuning only (0 in production)
 };
 hipError_t launch_update(hipStream_t s, const UpdateArgs& a);
 

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -52,7 +53,6 @@ struct oiva_plan {
     float* Ppart = nullptr;     // [nb][T][K]
     float* Plocal = nullptr;    // (T,K)
     float* R = nullptr;         // (T,K)
-    float* Rinv = nullptr;      // (T,K)
     float* wscale = nullptr;    // (K)
     float* Spart = nullptr;     // [nsplit][F][K][3]
     float2* Y = nullptr;        // (T,F,K), allocated on first demix
@@ -60,10 +60,12 @@ struct oiva_plan {
 
     CovGeom cov{};
     PowGeom pw{};
+    int n_cu = 256;
     int vpart_splits_alloc = 0;
 
     bool have_x = false, have_cx = false, have_w = false;
-    bool wscale_pending = false;  // Rinv / wscale computed, update not yet applied
+    bool wscale_pending = false;  // wscale computed (by the covariance pass), update not yet applied
+    int raw_weights = 0;          // test hook: R holds final 1/weights, no gamma normalisation
     int use_double = 0;
     int use_graph = 0;
     hipGraphExec_t graph_exec = nullptr;
@@ -72,27 +74,52 @@ struct oiva_plan {
 
 namespace {
 
+// Frame splits are chosen so that the grid is a whole number of "rounds" of what the chip holds at
+// once (CUs x resident workgroups per CU): a grid of 1.5 rounds runs as long as one of 2.
+int pick_splits(int capacity, int blocks_per_split, int T, int quantum, int min_frames, int max_rounds) {
+    int best = 1;
+    for (int r = 1; r <= max_rounds; ++r) {
+        const int ns = (r * capacity) / blocks_per_split;
+        if (ns < 1) continue;
+        const int tc = round_up(ceil_div(T, ns), quantum);
+        if (tc < min_frames && best > 1) break;
+        best = ns;
+        if (tc < min_frames) break;
+    }
+    return std::max(1, std::min(best, std::max(1, T / quantum)));
+}
+
 void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     CovGeom g;
     g.nbg = ceil_div(p->F, kBinsPerWave);
     g.kc = cov_sources_per_pass(p->M, p->K);
-    int nsplit = nsplit_req > 0 ? nsplit_req : std::max(1, (kTargetBlocks + g.nbg - 1) / g.nbg);
-    // at least 32 frames per split (2 steps per lane), frames per split a multiple of 16
-    int tc = round_up(ceil_div(p->T, nsplit), 16);
-    if (nsplit_req <= 0) tc = std::max(tc, 32);
-    g.tc = tc;
-    g.nsplit = ceil_div(p->T, tc);
+    const int nz = ceil_div(p->K, g.kc);
+    int nsplit = nsplit_req;
+    if (nsplit <= 0) {
+        int bpc = 2;
+        if (cov_blocks_per_cu(p->M, g.kc, &bpc) != hipSuccess || bpc < 1) bpc = 2;
+        // one round: every workgroup pays a fixed ~5 us (gamma prologue, LDS reduction epilogue), so
+        // fewer, longer workgroups win as long as the chip is full (measured 4 vs 8 vs 16 splits)
+        nsplit = pick_splits(p->n_cu * bpc, g.nbg * nz, p->T, 16, 128, 1);
+    }
+    g.tc = round_up(ceil_div(p->T, nsplit), 16);
+    g.nsplit = ceil_div(p->T, g.tc);
     p->cov = g;
 }
 
-void choose_pow_geom(oiva_plan* p) {
+void choose_pow_geom(oiva_plan* p, int nsplit_req) {
     PowGeom g;
     g.nb = ceil_div(p->F, kBinsPerWave * kWaves);
     g.kp = pow_sources_per_pass(p->M, p->K);
-    int nsplit = std::max(1, (kTargetBlocks + g.nb - 1) / g.nb);
+    const int nz = ceil_div(p->K, g.kp);
+    int nsplit = nsplit_req;
+    if (nsplit <= 0) {
+        // 3 workgroups (12 waves) per CU: more resident waves thrash the 32 KB L1 (measured: 2048
+        // workgroups run 3x slower than 768 on the headline shape), fewer expose HBM latency
+        nsplit = pick_splits(p->n_cu * 3, g.nb * nz, p->T, 4, 32, 1);
+    }
     int tcp = round_up(ceil_div(p->T, nsplit), 4);
-    tcp = std::max(tcp, 16);
-    tcp = std::min(tcp, kPowMaxFrames);
+    tcp = std::min(std::max(tcp, 4), kPowMaxFrames);
     g.tcp = tcp;
     g.nsplit = ceil_div(p->T, tcp);
     p->pw = g;
@@ -126,17 +153,16 @@ int stage_power(oiva_plan* p) {
     HIP_TRY(launch_power(p->stream, p->X, p->What, p->Ppart, p->T, p->F, p->M, p->K, p->pw));
     return OIVA_OK;
 }
-int stage_rsum(oiva_plan* p, const float* parts, int nparts) {
-    HIP_TRY(launch_rsum(p->stream, parts, nparts, p->R, p->T, p->K, p->model, p->F_total));
-    return OIVA_OK;
-}
-int stage_rfin(oiva_plan* p) {
-    HIP_TRY(launch_rfin(p->stream, p->R, p->Rinv, p->wscale, p->T, p->K, p->model));
-    p->wscale_pending = true;
+int stage_activation(oiva_plan* p, const float* parts, int nparts) {
+    HIP_TRY(launch_activation(p->stream, parts, nparts, p->R, p->T, p->K, p->model, p->F_total));
+    p->raw_weights = 0;
     return OIVA_OK;
 }
 int stage_cov(oiva_plan* p) {
-    HIP_TRY(launch_cov(p->stream, p->X, p->Rinv, p->Vpart, p->T, p->F, p->M, p->K, p->cov));
+    static const int ablate = getenv("OIVA_COV_ABLATE") ? 2 : 0;   // tuning only
+    HIP_TRY(launch_cov(p->stream, p->X, p->R, p->wscale, p->model, p->raw_weights | ablate, p->Vpart, p->T, p->F, p->M,
+                       p->K, p->cov));
+    p->wscale_pending = !p->raw_weights;
     return OIVA_OK;
 }
 int stage_update(oiva_plan* p, bool init_only) {
@@ -153,6 +179,7 @@ int stage_update(oiva_plan* p, bool init_only) {
     a.init_only = init_only ? 1 : 0;
     a.use_double = p->use_double & 1;
     a.layout = (p->use_double >> 1) & 1;
+    a.dbg = p->use_double >> 8;
     HIP_TRY(launch_update(p->stream, a));
     if (!init_only) p->wscale_pending = false;
     return OIVA_OK;
@@ -161,8 +188,7 @@ int stage_update(oiva_plan* p, bool init_only) {
 int one_iteration(oiva_plan* p) {
     int rc;
     if ((rc = stage_power(p))) return rc;
-    if ((rc = stage_rsum(p, p->Ppart, p->pw.nb))) return rc;
-    if ((rc = stage_rfin(p))) return rc;
+    if ((rc = stage_activation(p, p->Ppart, p->pw.nb))) return rc;
     if ((rc = stage_cov(p))) return rc;
     return stage_update(p, false);
 }
@@ -234,8 +260,13 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
         }
         p->own_stream = true;
     }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            p->n_cu = prop.multiProcessorCount;
+    }
     choose_cov_geom(p, 0);
-    choose_pow_geom(p);
+    choose_pow_geom(p, 0);
     const size_t nTK = (size_t)T * K;
     const size_t nFMM = (size_t)F * M * M;
     hipError_t e = hipSuccess;
@@ -246,8 +277,8 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     alloc((void**)&p->Cx, nFMM * sizeof(float));
     alloc((void**)&p->Ppart, (size_t)p->pw.nb * nTK * sizeof(float));
     alloc((void**)&p->Plocal, nTK * sizeof(float));
-    alloc((void**)&p->R, nTK * sizeof(float));
-    alloc((void**)&p->Rinv, nTK * sizeof(float));
+    alloc((void**)&p->R, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));   // zeroed tail rows: see cov_dma_kernel
+    if (e == hipSuccess) e = hipMemset(p->R, 0, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));
     alloc((void**)&p->wscale, (size_t)K * sizeof(float));
     alloc((void**)&p->scratch_c, (size_t)std::max(1, K) * nFMM * sizeof(float2));
     for (auto& ev : p->ev) {
@@ -272,7 +303,7 @@ int oiva_plan_destroy(oiva_plan* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     void* bufs[] = {p->X_owned, p->What, p->Cx,     p->Vpart, p->Ppart, p->Plocal, p->R,
-                    p->Rinv,    p->wscale, p->Spart, p->Y,     p->scratch_c};
+                    p->wscale, p->Spart, p->Y,     p->scratch_c};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& ev : p->ev)
@@ -313,7 +344,7 @@ int oiva_plan_covariance(oiva_plan* p) {
     CovGeom g = p->cov;
     g.kc = 1;
     // unit weights, one "source": partials land in Vpart laid out as [nsplit][F][1][M*M]
-    HIP_TRY(launch_cov(p->stream, p->X, nullptr, p->Vpart, p->T, p->F, p->M, 1, g));
+    HIP_TRY(launch_cov(p->stream, p->X, nullptr, nullptr, p->model, 0, p->Vpart, p->T, p->F, p->M, 1, g));
     HIP_TRY(launch_sum_parts(p->stream, p->Vpart, g.nsplit, p->Cx, (long long)p->F * p->M * p->M, 1.f / (float)p->T));
     p->have_cx = true;
     return OIVA_OK;
@@ -405,8 +436,7 @@ int oiva_plan_update(oiva_plan* p, const void* parts_dev, int nparts) {
     if (rc) return rc;
     NEED(parts_dev && nparts >= 1, OIVA_ERR_ARG, "need at least one part");
     DeviceGuard guard(p->device);
-    if ((rc = stage_rsum(p, (const float*)parts_dev, nparts))) return rc;
-    if ((rc = stage_rfin(p))) return rc;
+    if ((rc = stage_activation(p, (const float*)parts_dev, nparts))) return rc;
     if ((rc = stage_cov(p))) return rc;
     return stage_update(p, false);
 }
@@ -496,10 +526,9 @@ int oiva_plan_iterate_timed(oiva_plan* p, int n, float* total_ms, float* per_ker
         hipEvent_t* e = pool.data() + (size_t)it * per_it;
         err = hipEventRecord(e[0], p->stream);
         if (err == hipSuccess && !(rc = stage_power(p))) err = hipEventRecord(e[1], p->stream);
-        if (err == hipSuccess && !rc && !(rc = stage_rsum(p, p->Ppart, p->pw.nb))) err = hipEventRecord(e[2], p->stream);
-        if (err == hipSuccess && !rc && !(rc = stage_rfin(p))) err = hipEventRecord(e[3], p->stream);
-        if (err == hipSuccess && !rc && !(rc = stage_cov(p))) err = hipEventRecord(e[4], p->stream);
-        if (err == hipSuccess && !rc && !(rc = stage_update(p, false))) err = hipEventRecord(e[5], p->stream);
+        if (err == hipSuccess && !rc && !(rc = stage_activation(p, p->Ppart, p->pw.nb))) err = hipEventRecord(e[2], p->stream);
+        if (err == hipSuccess && !rc && !(rc = stage_cov(p))) err = hipEventRecord(e[3], p->stream);
+        if (err == hipSuccess && !rc && !(rc = stage_update(p, false))) err = hipEventRecord(e[4], p->stream);
     }
     if (err == hipSuccess && rc == OIVA_OK) err = hipStreamSynchronize(p->stream);
     for (int it = 0; it < n && err == hipSuccess && rc == OIVA_OK; ++it) {
@@ -534,6 +563,17 @@ int oiva_plan_set_cov_splits(oiva_plan* p, int nsplit) {
     return ensure_vpart(p);
 }
 
+int oiva_plan_set_pow_splits(oiva_plan* p, int nsplit) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(nsplit >= 0 && nsplit <= p->T, OIVA_ERR_ARG, "bad split count");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    int rc = drop_graph(p);
+    if (rc) return rc;
+    choose_pow_geom(p, nsplit);
+    return OIVA_OK;
+}
+
 int oiva_plan_use_graph(oiva_plan* p, int enable) {
     NEED(p, OIVA_ERR_ARG, "null plan");
     DeviceGuard guard(p->device);
@@ -548,7 +588,7 @@ int oiva_plan_set_precision(oiva_plan* p, int fp64_update) {
     HIP_TRY(hipStreamSynchronize(p->stream));
     int rc = drop_graph(p);
     if (rc) return rc;
-    p->use_double = fp64_update & 3;   // bit 0: fp64, bit 1 (test/tuning): row-per-lane layout
+    p->use_double = fp64_update;   // bit 0: fp64, bit 1: row-per-lane layout, bits 8+: ablation mask (tuning only)
     return OIVA_OK;
 }
 
@@ -556,8 +596,12 @@ int oiva_plan_set_precision(oiva_plan* p, int fp64_update) {
 int oiva_test_set_rinv(oiva_plan* p, const float* rinv_host) {
     NEED(p && rinv_host, OIVA_ERR_ARG, "null argument");
     DeviceGuard guard(p->device);
+    // the device keeps r, not 1/r: store the reciprocal and tell the covariance pass to skip gamma
+    std::vector<float> r((size_t)p->T * p->K);
+    for (size_t i = 0; i < r.size(); ++i) r[i] = 1.f / rinv_host[i];
     HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy(p->Rinv, rinv_host, (size_t)p->T * p->K * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->R, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice));
+    p->raw_weights = 1;
     return OIVA_OK;
 }
 
@@ -565,8 +609,22 @@ int oiva_test_get_rinv(oiva_plan* p, float* rinv_host, float* wscale_host) {
     NEED(p, OIVA_ERR_ARG, "null plan");
     DeviceGuard guard(p->device);
     HIP_TRY(hipStreamSynchronize(p->stream));
-    if (rinv_host)
-        HIP_TRY(hipMemcpy(rinv_host, p->Rinv, (size_t)p->T * p->K * sizeof(float), hipMemcpyDeviceToHost));
+    if (rinv_host) {
+        // same formula as oiva::activation_weight on the r the device holds
+        const int T = p->T, K = p->K;
+        std::vector<float> r((size_t)T * K);
+        HIP_TRY(hipMemcpy(r.data(), p->R, r.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int k = 0; k < K; ++k) {
+            double s = 0.;
+            for (int t = 0; t < T; ++t) s += (double)r[(size_t)t * K + k];
+            const float ginv = p->raw_weights ? 1.f : 1.f / (float)(s / (double)T);
+            for (int t = 0; t < T; ++t) {
+                float rn = r[(size_t)t * K + k] * ginv;
+                rn = rn < 1e-15f ? 1e-15f : rn;
+                rinv_host[(size_t)t * K + k] = 1.f / rn;
+            }
+        }
+    }
     if (wscale_host) HIP_TRY(hipMemcpy(wscale_host, p->wscale, (size_t)p->K * sizeof(float), hipMemcpyDeviceToHost));
     return OIVA_OK;
 }
@@ -623,6 +681,31 @@ int oiva_test_set_what(oiva_plan* p, const void* What_host) {
     HIP_TRY(hipMemcpy(p->What, What_host, (size_t)p->F * p->M * p->M * sizeof(float2), hipMemcpyHostToDevice));
     p->have_w = true;
     p->wscale_pending = false;
+    return OIVA_OK;
+}
+
+int oiva_test_time_stage(oiva_plan* p, int stage, int reps, float* avg_ms) {
+    int rc = check_ready(p);
+    if (rc) return rc;
+    NEED(reps >= 1 && avg_ms && stage >= 0 && stage < OIVA_N_STAGES, OIVA_ERR_ARG, "bad arguments");
+    DeviceGuard guard(p->device);
+    auto run = [&]() -> int {
+        switch (stage) {
+            case 0: return stage_power(p);
+            case 1: return stage_activation(p, p->Ppart, p->pw.nb);
+            case 2: return stage_cov(p);
+            default: return stage_update(p, false);
+        }
+    };
+    if ((rc = run())) return rc;  // warm
+    HIP_TRY(hipEventRecord(p->ev[0], p->stream));
+    for (int i = 0; i < reps; ++i)
+        if ((rc = run())) return rc;
+    HIP_TRY(hipEventRecord(p->ev[1], p->stream));
+    HIP_TRY(hipEventSynchronize(p->ev[1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev[0], p->ev[1]));
+    *avg_ms = ms / reps;
     return OIVA_OK;
 }
 

@@ -134,6 +134,9 @@ class Plan:
     def set_cov_splits(self, n):
         _lib.check(self.lib.oiva_plan_set_cov_splits(self.h, int(n)))
 
+    def set_pow_splits(self, n):
+        _lib.check(self.lib.oiva_plan_set_pow_splits(self.h, int(n)))
+
     def use_graph(self, enable=True):
         _lib.check(self.lib.oiva_plan_use_graph(self.h, 1 if enable else 0))
 
@@ -172,6 +175,14 @@ class Plan:
         What = np.ascontiguousarray(What, dtype=np.complex64)
         assert What.shape == (self.F, self.M, self.M)
         _lib.check(self.lib.oiva_test_set_what(self.h, _lib.ptr(What)))
+
+    def t_time_stage(self, stage, reps=20):
+        ms = C.c_float()
+        _lib.check(self.lib.oiva_test_time_stage(self.h, _lib.STAGE_NAMES.index(stage), int(reps), C.byref(ms)))
+        return ms.value
+
+    def t_set_flags(self, flags):
+        _lib.check(self.lib.oiva_plan_set_precision(self.h, int(flags)))
 
     def t_run_power(self):
         p = np.empty((self.T, self.K), np.float32)
