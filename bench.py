@@ -40,6 +40,19 @@ def cov_algorithmic_bytes(t, f, m, k):
     return 8 * t * f * m + 4 * t * k + 8 * f * k * m * m
 
 
+def measured_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same workload
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction; see
+    profiles/r01_pmc_hbm_traffic.json).  PMC counters need rocprofv3 around the process, so they cannot
+    be sampled from inside a plain bench run; None when the profile is absent."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch"]), os.path.relpath(path, REPO)
+    except Exception:
+        return None, None
+
+
 def synth_x_device(torch, device, f0, f1):
     """The iid complex64 workload, generated on the device (seeded per bin so that any sharding of
     the bins sees the same tensor)."""
@@ -108,9 +121,10 @@ def run_single(args):
     cov_ms = stages["weighted_cov"] / args.steps
     bytes_cov = cov_algorithmic_bytes(T, F, M, K)
     achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic("cov_dma_kernel<8, 2>")
     roofline = {"bound": "hbm", "kernel": "cov_dma_kernel<8,2> (weighted spatial covariance of both sources in one pass, overiva.py:179)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
+                "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
                 "stage_ms_per_step": {k: v / args.steps for k, v in stages.items()},
                 "event_timed_ms_per_step": total_ms / args.steps, "cov_splits": plan.cov_splits()}
     plan.close()
