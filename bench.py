@@ -161,7 +161,8 @@ def run_sharded(args):
         eng.set_x_device(X.data_ptr(), keepalive=X)
         eng.covariance()
         eng.set_w(None)
-        p_local = eng.exchange_buffer()
+        ppr = max(eng.power_parts(b[r + 1] - b[r]) for r in range(world))
+        p_local = eng.exchange_buffer(ppr)
         p_all = eng.new_gather_buffer(world)
 
         def step():

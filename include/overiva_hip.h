@@ -91,14 +91,18 @@ int oiva_plan_iterate(oiva_plan *p, int n);
 /*
  * The same iteration cut at its one cross-bin dependency (overiva.py:152-155: r needs all bins),
  * for bin-sharded multi-GPU runs:
- *   oiva_plan_power   : p_local[t,k] = sum over THIS plan's bins of |w_k^H x|^2  -> (T, K) float32
- *                       on the device (pointer from oiva_plan_power_buffer).
- *   (caller all-gathers the p_local of all shards into parts_dev, (nparts, T, K) float32)
- *   oiva_plan_update  : r from the fixed-order sum over parts, gamma, r_inv (overiva.py:152-173),
- *                       then the per-bin part of the iteration (overiva.py:161-167 W scaling, :176-190).
+ *   oiva_plan_power   : partial powers of THIS plan's bins, one (T, K) float32 part per batch of 64 bins:
+ *                       part[b][t,k] = sum over the batch's bins of |w_k^H x|^2.  They live in the device
+ *                       buffer returned by oiva_plan_power_buffer, laid out (parts_per_rank, T, K) with the
+ *                       parts this plan does not own left at zero (parts_per_rank = the largest batch
+ *                       count of any rank, so that every rank contributes an equally sized message).
+ *   (caller all-gathers the buffers of all ranks into parts_dev, (G * parts_per_rank, T, K) float32)
+ *   oiva_plan_update  : r from the sum over parts in buffer order (rank, then batch: fixed, so every
+ *                       rank gets the same bits), then the per-bin part of the iteration
+ *                       (overiva.py:158-173 gamma / 1/r, :161-167 W scaling, :176-190).
  */
 int oiva_plan_power(oiva_plan *p);
-int oiva_plan_power_buffer(oiva_plan *p, void **p_local_dev, long long *bytes);
+int oiva_plan_power_buffer(oiva_plan *p, int parts_per_rank, void **parts_dev, long long *bytes);
 int oiva_plan_update(oiva_plan *p, const void *parts_dev, int nparts);
 
 /*

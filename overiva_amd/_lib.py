@@ -42,7 +42,7 @@ SIGNATURES = {
     "oiva_plan_set_w": [_vp, _vp],
     "oiva_plan_iterate": [_vp, _i],
     "oiva_plan_power": [_vp],
-    "oiva_plan_power_buffer": [_vp, C.POINTER(_vp), C.POINTER(_ll)],
+    "oiva_plan_power_buffer": [_vp, _i, C.POINTER(_vp), C.POINTER(_ll)],
     "oiva_plan_update": [_vp, _vp, _i],
     "oiva_plan_demix": [_vp, _vp, _ll, _i],
     "oiva_plan_get_w": [_vp, _vp],

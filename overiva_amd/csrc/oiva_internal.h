@@ -45,6 +45,9 @@ constexpr int kPowMaxFrames = 512;
 //   Vpart [nsplit][F][K][M*M] packed partial sums (NOT divided by T)
 hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* wscale, int model, int raw, float* Vpart,
                       int T, int F, int M, int K, const CovGeom& g);
+// matrix-core variant for 9..16 channels (grid = F bins x nsplit, tc frames per split, tc even)
+hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float* wscale, int model, int raw,
+                           float* Vpart, int T, int F, int M, int K, int nsplit, int tc);
 int cov_sources_per_pass(int M, int K);
 hipError_t cov_blocks_per_cu(int M, int kc, int* n);
 bool cov_supported(int M);

@@ -50,7 +50,8 @@ struct oiva_plan {
     float2* What = nullptr;     // (F,M,M)
     float* Cx = nullptr;        // [F][M*M] packed, / T
     float* Vpart = nullptr;     // [nsplit][F][K][M*M]
-    float* Ppart = nullptr;     // [nb][T][K]
+    float* Ppart = nullptr;     // [nb (or more, zero padded)][T][K]
+    int ppart_alloc = 0;
     float* Plocal = nullptr;    // (T,K)
     float* R = nullptr;         // (T,K)
     float* wscale = nullptr;    // (K)
@@ -95,6 +96,19 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     g.kc = cov_sources_per_pass(p->M, p->K);
     const int nz = ceil_div(p->K, g.kc);
     int nsplit = nsplit_req;
+    if (p->M > 8) {
+        // matrix-core path: one workgroup per (bin, split); splits bound the length of the fp32
+        // accumulation chain (<= 512 frames) and keep >= 2 waves per SIMD when there are few bins
+        if (nsplit <= 0) {
+            nsplit = ceil_div(p->T, 512);
+            const int waves = p->F * ceil_div(p->K, 4);
+            while (waves * nsplit < 2 * 4 * p->n_cu && ceil_div(p->T, nsplit + 1) >= 64) ++nsplit;
+        }
+        g.tc = round_up(ceil_div(p->T, nsplit), 2);
+        g.nsplit = ceil_div(p->T, g.tc);
+        p->cov = g;
+        return;
+    }
     if (nsplit <= 0) {
         int bpc = 2;
         if (cov_blocks_per_cu(p->M, g.kc, &bpc) != hipSuccess || bpc < 1) bpc = 2;
@@ -236,7 +250,7 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     NEED(K >= 1 && K <= M, OIVA_ERR_ARG, "n_src must be in 1..n_chan");
     NEED(model == OIVA_MODEL_LAPLACE || model == OIVA_MODEL_GAUSS, OIVA_ERR_ARG, "unknown model");
     NEED(F_total >= F, OIVA_ERR_ARG, "F_total must be >= F");
-    NEED(cov_supported(M), OIVA_ERR_ARG, "this build supports up to 8 channels in the covariance pass");
+    NEED(cov_supported(M), OIVA_ERR_ARG, "unsupported number of channels");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     NEED(device >= 0 && device < ndev, OIVA_ERR_ARG, "no such device");
@@ -276,6 +290,7 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     alloc((void**)&p->What, nFMM * sizeof(float2));
     alloc((void**)&p->Cx, nFMM * sizeof(float));
     alloc((void**)&p->Ppart, (size_t)p->pw.nb * nTK * sizeof(float));
+    p->ppart_alloc = p->pw.nb;
     alloc((void**)&p->Plocal, nTK * sizeof(float));
     alloc((void**)&p->R, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));   // zeroed tail rows: see cov_dma_kernel
     if (e == hipSuccess) e = hipMemset(p->R, 0, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));
@@ -419,15 +434,26 @@ int oiva_plan_power(oiva_plan* p) {
     int rc = check_ready(p);
     if (rc) return rc;
     DeviceGuard guard(p->device);
-    if ((rc = stage_power(p))) return rc;
-    HIP_TRY(launch_sum_parts(p->stream, p->Ppart, p->pw.nb, p->Plocal, (long long)p->T * p->K, 1.f));
-    return OIVA_OK;
+    return stage_power(p);
 }
 
-int oiva_plan_power_buffer(oiva_plan* p, void** p_local_dev, long long* bytes) {
-    NEED(p && p_local_dev, OIVA_ERR_ARG, "null argument");
-    *p_local_dev = p->Plocal;
-    if (bytes) *bytes = (long long)p->T * p->K * (long long)sizeof(float);
+int oiva_plan_power_buffer(oiva_plan* p, int parts_per_rank, void** parts_dev, long long* bytes) {
+    NEED(p && parts_dev, OIVA_ERR_ARG, "null argument");
+    NEED(parts_per_rank >= p->pw.nb, OIVA_ERR_ARG, "parts_per_rank smaller than this plan's own bin batches");
+    DeviceGuard guard(p->device);
+    const size_t part = (size_t)p->T * p->K * sizeof(float);
+    if (parts_per_rank > p->ppart_alloc) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        int rc = drop_graph(p);
+        if (rc) return rc;
+        if (p->Ppart) HIP_TRY(hipFree(p->Ppart));
+        p->Ppart = nullptr;
+        HIP_TRY(hipMalloc(&p->Ppart, part * parts_per_rank));
+        HIP_TRY(hipMemset(p->Ppart, 0, part * parts_per_rank));   // parts beyond nb stay zero
+        p->ppart_alloc = parts_per_rank;
+    }
+    *parts_dev = p->Ppart;
+    if (bytes) *bytes = (long long)(part * parts_per_rank);
     return OIVA_OK;
 }
 

@@ -88,9 +88,15 @@ class Plan:
     def power(self):
         _lib.check(self.lib.oiva_plan_power(self.h))
 
-    def power_buffer(self):
+    BINS_PER_PART = 64   # one partial-power part per batch of 64 bins (power kernel workgroup)
+
+    @classmethod
+    def power_parts(cls, n_bins):
+        return (n_bins + cls.BINS_PER_PART - 1) // cls.BINS_PER_PART
+
+    def power_buffer(self, parts_per_rank):
         p, nbytes = C.c_void_p(), C.c_longlong()
-        _lib.check(self.lib.oiva_plan_power_buffer(self.h, C.byref(p), C.byref(nbytes)))
+        _lib.check(self.lib.oiva_plan_power_buffer(self.h, int(parts_per_rank), C.byref(p), C.byref(nbytes)))
         return p.value, nbytes.value
 
     def update(self, parts_dev_ptr, nparts):

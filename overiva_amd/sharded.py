@@ -4,7 +4,7 @@ Every per-iteration quantity of the algorithm is per-bin except the source activ
 ``r[t,k] = f(sum_f |y_{t,f,k}|^2)`` (reference ``overiva.py:152-155``).  Each rank therefore owns a
 contiguous range of bins end to end (its slice of X, Cx, V, W_hat, Y never leaves its GPU) and one
 collective per iteration exchanges the per-rank partial powers: an all-gather of (T, K) float32
-followed by a sum in rank order on every rank (bitwise identical ``r`` everywhere; an all-reduce
+(one part per 64-bin batch, zero padded to the same count on every rank) followed by a sum in buffer order on every rank (bitwise identical ``r`` everywhere; an all-reduce
 would leave the order to the ring).  With backend "nccl" this is RCCL over xGMI; the payload is
 tiny (T*K*4 bytes per rank), so the step is latency bound.
 
@@ -65,15 +65,22 @@ class HipEngine:
     def stream_ctx(self):
         return self.torch.cuda.stream(self.stream)
 
-    def exchange_buffer(self):
-        """(T, K) float32 device tensor aliasing the plan's local-power buffer"""
-        ptr, nbytes = self.plan.power_buffer()
+    @staticmethod
+    def power_parts(n_bins):
+        from .plan import Plan
+
+        return Plan.power_parts(n_bins)
+
+    def exchange_buffer(self, parts_per_rank):
+        """(parts_per_rank * T, K) float32 device tensor aliasing the plan's partial-power buffer"""
+        ptr, nbytes = self.plan.power_buffer(parts_per_rank)
+        self.ppr = parts_per_rank
 
         class _Mem:
             pass
 
         m = _Mem()
-        m.__cuda_array_interface__ = {"shape": (self.T, self.K), "typestr": "<f4", "data": (ptr, False),
+        m.__cuda_array_interface__ = {"shape": (parts_per_rank * self.T, self.K), "typestr": "<f4", "data": (ptr, False),
                                       "version": 2, "strides": None}
         t = self.torch.as_tensor(m, device=self.device)
         assert t.data_ptr() == ptr, "torch copied the exchange buffer instead of aliasing it"
@@ -81,7 +88,7 @@ class HipEngine:
 
     def new_gather_buffer(self, world):
         # rank-major concatenation along dim 0 == (world, T, K) in memory (the layout every backend accepts)
-        return self.torch.empty((world * self.T, self.K), dtype=self.torch.float32, device=self.device)
+        return self.torch.empty((world * self.ppr * self.T, self.K), dtype=self.torch.float32, device=self.device)
 
     def set_x(self, X, f0):
         self.plan.set_x(X, f0)
@@ -142,7 +149,9 @@ class BinShardedSolver:
             self.engine = HipEngine(T, self.f1 - self.f0, M, K, model, F, dev)
         else:
             self.engine = engine_factory(T, self.f1 - self.f0, M, K, model, F)
-        self.p_local = self.engine.exchange_buffer()
+        # every rank sends the same number of (T, K) parts: the largest batch count of any shard
+        ppr = max(self.engine.power_parts(self.bounds[r + 1] - self.bounds[r]) for r in range(self.world))
+        self.p_local = self.engine.exchange_buffer(ppr)
         self.p_all = self.engine.new_gather_buffer(self.world)
 
     # ---- stages ---------------------------------------------------------------------------------

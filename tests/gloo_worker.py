@@ -17,9 +17,13 @@ class OracleEngine:
 
         self.torch = torch
         self.T, self.F, self.M, self.K, self.model, self.F_total = T, F_local, M, K, model, F_total
-        self._p = torch.zeros((T, K), dtype=torch.float32)
+    @staticmethod
+    def power_parts(n_bins):
+        return (n_bins + 3) // 4          # test engine: one part per 4 bins, so shards differ in part count
 
-    def exchange_buffer(self):
+    def exchange_buffer(self, parts_per_rank):
+        self.ppr = parts_per_rank
+        self._p = self.torch.zeros((parts_per_rank * self.T, self.K), dtype=self.torch.float32)
         return self._p
 
     def stream_ctx(self):
@@ -28,7 +32,7 @@ class OracleEngine:
         return contextlib.nullcontext()
 
     def new_gather_buffer(self, world):
-        return self.torch.empty((world * self.T, self.K), dtype=self.torch.float32)
+        return self.torch.empty((world * self.ppr * self.T, self.K), dtype=self.torch.float32)
 
     def set_x(self, X, f0):
         self.X = np.asarray(X)[:, f0:f0 + self.F, :].astype(np.complex128)
@@ -49,8 +53,11 @@ class OracleEngine:
     def power(self):
         from oracle import overiva_oracle as orc
 
-        p = orc.demix_power(self.X, self.What[:, :, :self.K])
-        self._p.copy_(self.torch.from_numpy(p.astype(np.float32)))
+        buf = self._p.numpy().reshape(self.ppr, self.T, self.K)
+        buf[:] = 0.0
+        for part in range(self.power_parts(self.F)):
+            sl = slice(4 * part, min(4 * part + 4, self.F))
+            buf[part] = orc.demix_power(self.X[:, sl], self.What[sl, :, :self.K]).astype(np.float32)
 
     def update(self, parts):
         from oracle import overiva_oracle as orc
