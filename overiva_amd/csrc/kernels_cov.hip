@@ -426,9 +426,9 @@ int cov_sources_per_pass(int M, int K) {
     return kc;
 }
 
-hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* wscale, int model, int raw, float* Vpart,
-                      int T, int F, int M, int K, const CovGeom& g) {
-    if (M > 8) return launch_cov_mfma(s, X, R, wscale, model, raw, Vpart, T, F, M, K, g.nsplit, g.tc);
+hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
+                      float* Vpart, int T, int F, int M, int K, const CovGeom& g) {
+    if (M > 8) return launch_cov_mfma(s, X, R, Wt, wscale, model, raw, Vpart, T, F, M, K, g.nsplit, g.tc);
     return dispatch_cov(M, g.kc, R == nullptr, [&](CovKernel kern, int KC) {
         dim3 grid(g.nbg, g.nsplit, (K + KC - 1) / KC);
         kern<<<grid, dim3(kBlock), 0, s>>>(X, R, wscale, model, raw, Vpart, T, F, K, g.tc);

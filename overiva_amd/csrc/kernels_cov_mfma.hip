@@ -19,30 +19,26 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// gamma_k = mean_t R[t,k], one wave, fixed order
-__device__ __forceinline__ float wave_gamma(const float* __restrict__ R, int T, int K, int k) {
-    const int lane = threadIdx.x & 63;
-    double s = 0.;
-    for (int t0 = lane; t0 < T; t0 += 64 * 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = t0 + 64 * u;
-            v[u] = R[(size_t)(t < T ? t : T - 1) * K + k];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += (t0 + 64 * u < T) ? (double)v[u] : 0.;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    return (float)(s / (double)T);
-}
-
 constexpr int kPairUnroll = 4;   // frame pairs whose loads are issued together
 
+// Final weights w[t,k] = 1 / max(r[t,k] / gamma_k, eps) (overiva.py:158-173) for the matrix-core kernel, which
+// has no VALU slots to spare for the divide (4 MFMAs of 64 cycles per frame pair and wave).  One workgroup
+// per 256 frames; every workgroup derives gamma itself (block_gamma, fixed order).
+__global__ __launch_bounds__(kBlock) void weights_kernel(const float* __restrict__ R, float* __restrict__ Wt,
+                                                         float* __restrict__ wscale, int model, int raw, int T, int K) {
+    __shared__ double scratch[kWaves];
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    for (int k = 0; k < K; ++k) {
+        const float gamma = block_gamma(R, T, K, k, scratch);
+        const float ginv = (raw & 1) ? 1.f : 1.f / gamma;
+        if (t < T) Wt[(size_t)t * K + k] = activation_weight(R[(size_t)t * K + k], ginv);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && wscale != nullptr)
+            wscale[k] = model == OIVA_MODEL_LAPLACE ? gamma : sqrtf(gamma);   // overiva.py:163 / :167
+    }
+}
+
 template <int KW, bool UNIT>
-__global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__ Xf, const float* __restrict__ R,
-                                                       float* __restrict__ wscale, int model, int raw,
+__global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__ Xf, const float* __restrict__ Wt,
                                                        float* __restrict__ Vpart, int T, int F, int M, int K, int tc) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -57,53 +53,64 @@ __global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__
     const bool ivalid = i32 < M2;
     const int NA = M * M;
 
-    float ginv[KW];
-#pragma unroll
-    for (int kk = 0; kk < KW; ++kk) {
-        ginv[kk] = 1.f;
-        if constexpr (!UNIT) {
-            const int k = k0 + kk;
-            const float gamma = wave_gamma(R, T, K, k < K ? k : K - 1);
-            if (!(raw & 1)) ginv[kk] = 1.f / gamma;
-            if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && k < K && wscale != nullptr)
-                wscale[k] = model == OIVA_MODEL_LAPLACE ? gamma : sqrtf(gamma);   // overiva.py:163 / :167
-        }
-    }
-
     f32x16 acc[KW];
 #pragma unroll
     for (int kk = 0; kk < KW; ++kk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[kk][r] = 0.f;
 
+    // The matrix pipe needs 4 MFMAs x 64 cycles per frame pair and wave, and four waves share a SIMD, so
+    // the VALU budget is ~60 issue cycles per pair and wave: x is one vector load through a running
+    // pointer (no per-load 64-bit multiplies), the weights of the pair's two frames are wave-uniform and
+    // come through the scalar cache (one select per weight), masks are multiplications.
     const size_t frame_stride = (size_t)F * M2;                       // floats per frame
-    const float* px = Xf + (size_t)f * M2 + (ivalid ? i32 : 0);
-    for (int p0 = 0; p0 < npairs; p0 += kPairUnroll) {
-        float x[kPairUnroll], rv[kPairUnroll][KW];
+    const size_t pair_stride = 2 * frame_stride;
+    const float xmask = ivalid ? 1.f : 0.f;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int kcl[KW];
+    float kmask[KW];
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+        const int k = wave_u * KW + kk;
+        kcl[kk] = k < K ? k : K - 1;
+        kmask[kk] = k < K ? 1.f : 0.f;
+    }
+    const float* px = Xf + (size_t)f * M2 + (ivalid ? i32 : 0) + (size_t)(t_begin + half) * frame_stride;
+    const int nfull = (t_end - t_begin) >> 1;                          // pairs with both frames inside the split
+    int p0 = 0;
+    for (; p0 + kPairUnroll <= nfull; p0 += kPairUnroll) {
+        float x[kPairUnroll];
 #pragma unroll
         for (int u = 0; u < kPairUnroll; ++u) {
-            const int t = t_begin + 2 * (p0 + u) + half;
-            const int tcl = t < t_end ? t : T - 1;
-            x[u] = px[(size_t)tcl * frame_stride];
-            if constexpr (!UNIT) {
-#pragma unroll
-                for (int kk = 0; kk < KW; ++kk) {
-                    const int k = k0 + kk;
-                    rv[u][kk] = R[(size_t)tcl * K + (k < K ? k : K - 1)];
-                }
-            }
+            x[u] = *px;
+            px += pair_stride;
         }
 #pragma unroll
         for (int u = 0; u < kPairUnroll; ++u) {
-            const int t = t_begin + 2 * (p0 + u) + half;
-            const bool live = (p0 + u < npairs) && (t < t_end) && ivalid;
-            const float xv = live ? x[u] : 0.f;
+            const float xv = x[u] * xmask;
+            const float* w0 = Wt + (size_t)(t_begin + 2 * (p0 + u)) * K;     // uniform: scalar loads
 #pragma unroll
             for (int kk = 0; kk < KW; ++kk) {
-                float w = 1.f;
-                if constexpr (!UNIT) w = (k0 + kk < K) ? activation_weight(rv[u][kk], ginv[kk]) : 0.f;
-                acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv * w, xv, acc[kk], 0, 0, 0);
+                float a = xv;
+                if constexpr (!UNIT) {
+                    const float wa = w0[kcl[kk]], wb = w0[K + kcl[kk]];
+                    a = xv * ((half ? wb : wa) * kmask[kk]);
+                }
+                acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xv, acc[kk], 0, 0, 0);
             }
+        }
+    }
+    // tail: remaining pairs one at a time; the last one may have only its first frame inside the split
+    for (; p0 < npairs; ++p0) {
+        const int t = t_begin + 2 * p0 + half;
+        const float live = t < t_end ? xmask : 0.f;
+        const int tcl = t < t_end ? t : T - 1;
+        const float xv = Xf[(size_t)tcl * frame_stride + (size_t)f * M2 + (ivalid ? i32 : 0)] * live;
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) {
+            float a = xv;
+            if constexpr (!UNIT) a = xv * (Wt[(size_t)tcl * K + kcl[kk]] * kmask[kk]);
+            acc[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xv, acc[kk], 0, 0, 0);
         }
     }
 
@@ -141,9 +148,13 @@ __global__ __launch_bounds__(256) void cov_mfma_kernel(const float* __restrict__
 
 int cov_mfma_sources_per_wave(int K) { return K == 1 ? 1 : (K == 2 ? 2 : 4); }
 
-hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float* wscale, int model, int raw,
+hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                            float* Vpart, int T, int F, int M, int K, int nsplit, int tc) {
     const bool unit = R == nullptr;
+    if (!unit) {
+        if (Wt == nullptr) return hipErrorInvalidValue;
+        weights_kernel<<<dim3((T + kBlock - 1) / kBlock), dim3(kBlock), 0, s>>>(R, Wt, wscale, model, raw, T, K);
+    }
     const int kw = unit ? 1 : cov_mfma_sources_per_wave(K);
     const int waves = (K + kw - 1) / kw;
     if (waves > 4 || M > 16) return hipErrorInvalidValue;
@@ -151,13 +162,13 @@ hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float
     dim3 block(64 * waves);
     const float* Xf = reinterpret_cast<const float*>(X);
     if (unit)
-        cov_mfma_kernel<1, true><<<grid, block, 0, s>>>(Xf, R, wscale, model, raw, Vpart, T, F, M, K, tc);
+        cov_mfma_kernel<1, true><<<grid, block, 0, s>>>(Xf, Wt, Vpart, T, F, M, K, tc);
     else if (kw == 1)
-        cov_mfma_kernel<1, false><<<grid, block, 0, s>>>(Xf, R, wscale, model, raw, Vpart, T, F, M, K, tc);
+        cov_mfma_kernel<1, false><<<grid, block, 0, s>>>(Xf, Wt, Vpart, T, F, M, K, tc);
     else if (kw == 2)
-        cov_mfma_kernel<2, false><<<grid, block, 0, s>>>(Xf, R, wscale, model, raw, Vpart, T, F, M, K, tc);
+        cov_mfma_kernel<2, false><<<grid, block, 0, s>>>(Xf, Wt, Vpart, T, F, M, K, tc);
     else
-        cov_mfma_kernel<4, false><<<grid, block, 0, s>>>(Xf, R, wscale, model, raw, Vpart, T, F, M, K, tc);
+        cov_mfma_kernel<4, false><<<grid, block, 0, s>>>(Xf, Wt, Vpart, T, F, M, K, tc);
     return hipGetLastError();
 }
 

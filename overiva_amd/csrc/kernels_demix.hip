@@ -317,7 +317,7 @@ hipError_t launch_write_one(hipStream_t s, const float2* X, const float2* What, 
 }  // namespace
 
 int pow_sources_per_pass(int M, int K) {
-    if (K >= 3 && M <= 8) return 4;
+    if (K >= 3) return 4;
     if (K >= 2) return 2;
     return 1;
 }
@@ -327,9 +327,7 @@ hipError_t pow_blocks_per_cu(int M, int kp, int tcp, int* n) {
 #define CALL(MM)                                                                                                   \
     if (kp == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, power_kernel<MM, 1>, kBlock, shmem);       \
     if (kp == 2) return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, power_kernel<MM, 2>, kBlock, shmem);       \
-    if constexpr (MM <= 8) {                                                                                       \
-        if (kp == 4) return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, power_kernel<MM, 4>, kBlock, shmem);   \
-    }
+    if (kp == 4) return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, power_kernel<MM, 4>, kBlock, shmem);
     OIVA_DISPATCH_M(CALL)
 #undef CALL
     return hipErrorInvalidValue;
@@ -340,9 +338,7 @@ hipError_t launch_power(hipStream_t s, const float2* X, const float2* What, floa
 #define CALL(MM)                                                                                        \
     if (g.kp == 1) return launch_power_one<MM, 1>(s, X, What, Ppart, T, F, K, g);                       \
     if (g.kp == 2) return launch_power_one<MM, 2>(s, X, What, Ppart, T, F, K, g);                       \
-    if constexpr (MM <= 8) {                                                                            \
-        if (g.kp == 4) return launch_power_one<MM, 4>(s, X, What, Ppart, T, F, K, g);                   \
-    }
+    if (g.kp == 4) return launch_power_one<MM, 4>(s, X, What, Ppart, T, F, K, g);
     OIVA_DISPATCH_M(CALL)
 #undef CALL
     return hipErrorInvalidValue;

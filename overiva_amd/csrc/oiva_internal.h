@@ -43,10 +43,11 @@ constexpr int kPowMaxFrames = 512;
 //   weights: w[t,k] = 1 / max(R[t,k] / gamma_k, eps), gamma_k = mean_t R (overiva.py:158-173); with raw != 0
 //   gamma is taken as 1.  wscale (K): out, gamma (laplace) | sqrt(gamma) (gauss), written by one workgroup.
 //   Vpart [nsplit][F][K][M*M] packed partial sums (NOT divided by T)
-hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* wscale, int model, int raw, float* Vpart,
-                      int T, int F, int M, int K, const CovGeom& g);
+hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
+                      float* Vpart, int T, int F, int M, int K, const CovGeom& g);
 // matrix-core variant for 9..16 channels (grid = F bins x nsplit, tc frames per split, tc even)
-hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float* wscale, int model, int raw,
+//   Wt (T,K): scratch for the final weights (written by a small pre-pass)
+hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                            float* Vpart, int T, int F, int M, int K, int nsplit, int tc);
 int cov_sources_per_pass(int M, int K);
 hipError_t cov_blocks_per_cu(int M, int kc, int* n);

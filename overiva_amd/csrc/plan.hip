@@ -174,8 +174,8 @@ int stage_activation(oiva_plan* p, const float* parts, int nparts) {
 }
 int stage_cov(oiva_plan* p) {
     static const int ablate = getenv("OIVA_COV_ABLATE") ? 2 : 0;   // tuning only
-    HIP_TRY(launch_cov(p->stream, p->X, p->R, p->wscale, p->model, p->raw_weights | ablate, p->Vpart, p->T, p->F, p->M,
-                       p->K, p->cov));
+    HIP_TRY(launch_cov(p->stream, p->X, p->R, p->Plocal /* weights scratch, (T,K) */, p->wscale, p->model,
+                       p->raw_weights | ablate, p->Vpart, p->T, p->F, p->M, p->K, p->cov));
     p->wscale_pending = !p->raw_weights;
     return OIVA_OK;
 }
@@ -359,7 +359,7 @@ int oiva_plan_covariance(oiva_plan* p) {
     CovGeom g = p->cov;
     g.kc = 1;
     // unit weights, one "source": partials land in Vpart laid out as [nsplit][F][1][M*M]
-    HIP_TRY(launch_cov(p->stream, p->X, nullptr, nullptr, p->model, 0, p->Vpart, p->T, p->F, p->M, 1, g));
+    HIP_TRY(launch_cov(p->stream, p->X, nullptr, nullptr, nullptr, p->model, 0, p->Vpart, p->T, p->F, p->M, 1, g));
     HIP_TRY(launch_sum_parts(p->stream, p->Vpart, g.nsplit, p->Cx, (long long)p->F * p->M * p->M, 1.f / (float)p->T));
     p->have_cx = true;
     return OIVA_OK;
