@@ -174,11 +174,13 @@ def run_sharded(args):
             step()
         stream.synchronize()
         graph = None
-        if args.graph:
+        spg = 8            # iterations per captured graph (kernels + the RCCL all-gather)
+        if args.graph and args.steps >= spg:
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=stream):
-                    step()
+                    for _ in range(spg):
+                        step()
                 graph.replay()
                 stream.synchronize()
             except Exception as e:  # capture of the collective not supported: stay eager
@@ -188,11 +190,14 @@ def run_sharded(args):
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            if graph is not None:
+        done = 0
+        if graph is not None:
+            while done + spg <= args.steps:
                 graph.replay()
-            else:
-                step()
+                done += spg
+        while done < args.steps:       # remainder (or everything, when eager): exactly K steps in total
+            step()
+            done += 1
         stream.synchronize()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0

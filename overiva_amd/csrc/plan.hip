@@ -35,7 +35,7 @@ int fail(int code, const std::string& msg) {
 int round_up(int a, int b) { return (a + b - 1) / b * b; }
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-constexpr int kTargetBlocks = 768;  // ~3 workgroups of 4 waves per CU on 256 CUs
+constexpr int kGraphBatch = 8;       // iterations per captured graph
 
 }  // namespace
 
@@ -69,7 +69,8 @@ struct oiva_plan {
     int raw_weights = 0;          // test hook: R holds final 1/weights, no gamma normalisation
     int use_double = 0;
     int use_graph = 0;
-    hipGraphExec_t graph_exec = nullptr;
+    hipGraphExec_t graph_exec = nullptr;        // one iteration
+    hipGraphExec_t graph_batch_exec = nullptr;  // kGraphBatch iterations
     hipEvent_t ev[2] = {};
 };
 
@@ -115,6 +116,10 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         // one round: every workgroup pays a fixed ~5 us (gamma prologue, LDS reduction epilogue), so
         // fewer, longer workgroups win as long as the chip is full (measured 4 vs 8 vs 16 splits)
         nsplit = pick_splits(p->n_cu * bpc, g.nbg * nz, p->T, 16, 128, 1);
+        // the update kernel adds the nsplit partials of every matrix element one dependent round of loads
+        // per 4 splits: beyond 16 splits that costs more there than the fuller grid saves here (measured
+        // on a 256-bin shard: update 19.4 -> 15.6 us, covariance unchanged)
+        nsplit = std::min(nsplit, 16);
     }
     g.tc = round_up(ceil_div(p->T, nsplit), 16);
     g.nsplit = ceil_div(p->T, g.tc);
@@ -143,6 +148,10 @@ int drop_graph(oiva_plan* p) {
     if (p->graph_exec) {
         HIP_TRY(hipGraphExecDestroy(p->graph_exec));
         p->graph_exec = nullptr;
+    }
+    if (p->graph_batch_exec) {
+        HIP_TRY(hipGraphExecDestroy(p->graph_batch_exec));
+        p->graph_batch_exec = nullptr;
     }
     return OIVA_OK;
 }
@@ -317,6 +326,7 @@ int oiva_plan_destroy(oiva_plan* p) {
     DeviceGuard guard(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->graph_batch_exec) (void)hipGraphExecDestroy(p->graph_batch_exec);
     void* bufs[] = {p->X_owned, p->What, p->Cx,     p->Vpart, p->Ppart, p->Plocal, p->R,
                     p->wscale, p->Spart, p->Y,     p->scratch_c};
     for (void* b : bufs)
@@ -406,22 +416,33 @@ int oiva_plan_iterate(oiva_plan* p, int n) {
     DeviceGuard guard(p->device);
     if (n == 0) return OIVA_OK;
     if (p->use_graph) {
-        if (!p->graph_exec) {
-            // the update inside the graph always consumes wscale (rfin runs before it in every iteration)
+        // Two captured graphs: kGraphBatch iterations (amortises the ~10-16 us replay floor, which matters when
+        // an iteration is tens of microseconds) and a single iteration for the remainder.
+        auto capture = [&](int iters, hipGraphExec_t* exec) -> int {
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-            rc = one_iteration(p);
+            int r = OIVA_OK;
+            for (int i = 0; i < iters && r == OIVA_OK; ++i) r = one_iteration(p);
             hipError_t e = hipStreamEndCapture(p->stream, &graph);
-            if (rc) {
+            if (r) {
                 if (graph) (void)hipGraphDestroy(graph);
-                return rc;
+                return r;
             }
             HIP_TRY(e);
-            e = hipGraphInstantiate(&p->graph_exec, graph, nullptr, nullptr, 0);
+            e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             HIP_TRY(e);
+            return OIVA_OK;
+        };
+        int left = n;
+        if (left >= kGraphBatch) {
+            if (!p->graph_batch_exec && (rc = capture(kGraphBatch, &p->graph_batch_exec))) return rc;
+            for (; left >= kGraphBatch; left -= kGraphBatch) HIP_TRY(hipGraphLaunch(p->graph_batch_exec, p->stream));
         }
-        for (int i = 0; i < n; ++i) HIP_TRY(hipGraphLaunch(p->graph_exec, p->stream));
+        if (left > 0) {
+            if (!p->graph_exec && (rc = capture(1, &p->graph_exec))) return rc;
+            for (; left > 0; --left) HIP_TRY(hipGraphLaunch(p->graph_exec, p->stream));
+        }
         p->wscale_pending = false;
         return OIVA_OK;
     }

@@ -141,8 +141,15 @@ def overiva(
 class _SingleDevice:
     """all bins on one GPU"""
 
+    # hipGraph replay pays off once an iteration is hundreds of microseconds (cheaper kernel boundaries);
+    # below that eager launches are faster (measured: 513x1000x4 30.4k it/s eager vs 26.5k replayed,
+    # 2048x4000x8 4.1k eager vs 4.5k replayed)
+    GRAPH_MIN_ELEMENTS = 1 << 23
+
     def __init__(self, T, F, M, K, model):
         self.plan = Plan(T, F, M, K, model, device=get_device())
+        if T * F * M >= self.GRAPH_MIN_ELEMENTS:
+            self.plan.use_graph(True)
 
     def set_x(self, X):
         self.plan.set_x(X)
