@@ -246,6 +246,36 @@ def test_odd_shapes_against_oracle(oa, shape):
         assert eW < max(TOL, 5 * floor) and eY < max(TOL, 5 * floor)
 
 
+@pytest.mark.parametrize("shape", [(5, 1, 1, 1), (17, 3, 2, 1), (33, 70, 3, 3), (5000, 2, 4, 2), (16, 16, 8, 8),
+                                   (2, 5, 2, 2), (1000, 1, 6, 2)])
+def test_ragged_and_extreme_shapes(oa, shape):
+    """frames not a multiple of the 16-frame step, fewer bins than a 16-bin wave, single bin / channel,
+    very long and very short frame axes"""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F, M, seed=7 + sum(shape))
+    Y, W = oa.overiva(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
+    Yr, Wr = orc.overiva_staged(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
+    if not np.all(np.isfinite(Wr)):
+        pytest.skip("degenerate for the algorithm itself (oracle non-finite)")
+    floor = _c64_floor(lambda: orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)[1], Wr)
+    assert orc.rel_err(W, Wr) < max(TOL, 5 * floor) and orc.rel_err(Y, Yr) < max(TOL, 5 * floor)
+
+
+def test_config1_shape_against_oracle(oa):
+    """BASELINE.json configs[0] shape: 2049 bins x ~160 frames x 4 mics / 2 src, complex128 in, 20 iterations,
+    proj_back and the callback every 10 epochs (overiva_oneshot.py -a overiva -m 4 -s 2 -n 20)"""
+    X = orc.synth_mixture(160, 2049, 4, 2, seed=3).astype(np.complex128)
+    got, ref_got = [], []
+    Y = oa.overiva(X, n_src=2, n_iter=20, proj_back=True, callback=lambda y: got.append(y.copy()))
+    Yr = orc.overiva_staged(X, n_src=2, n_iter=20, proj_back=True, callback=lambda y: ref_got.append(y.copy()))
+    floor = _c64_floor(lambda: orc.overiva_faithful(X.astype(np.complex64), n_src=2, n_iter=20, proj_back=True), Yr)
+    e = orc.rel_err(Y, Yr)
+    print(f"\n[parity] cfg1 shape mixture 20 its proj_back: Y err {e:.2e} (reference c64 floor {floor:.1e})")
+    assert Y.dtype == np.complex128 and len(got) == len(ref_got) == 2
+    assert e < max(TOL, 5 * floor)
+    assert orc.rel_err(got[1], ref_got[1]) < max(TOL, 5 * floor)
+
+
 def test_errors(oa):
     X = orc.synth_iid(32, 4, 3, seed=1)
     with pytest.raises(ValueError):
