@@ -105,7 +105,7 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
             const int waves = p->F * ceil_div(p->K, 4);
             while (waves * nsplit < 2 * 4 * p->n_cu && ceil_div(p->T, nsplit + 1) >= 64) ++nsplit;
         }
-        g.tc = round_up(ceil_div(p->T, nsplit), 2);
+        g.tc = round_up(ceil_div(p->T, nsplit), 4);
         g.nsplit = ceil_div(p->T, g.tc);
         p->cov = g;
         return;
@@ -300,7 +300,7 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     alloc((void**)&p->Cx, nFMM * sizeof(float));
     alloc((void**)&p->Ppart, (size_t)p->pw.nb * nTK * sizeof(float));
     p->ppart_alloc = p->pw.nb;
-    alloc((void**)&p->Plocal, nTK * sizeof(float));
+    alloc((void**)&p->Plocal, std::max(nTK, (size_t)T * 16) * sizeof(float));   // also the (T, 16) weights scratch
     alloc((void**)&p->R, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));   // zeroed tail rows: see cov_dma_kernel
     if (e == hipSuccess) e = hipMemset(p->R, 0, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));
     alloc((void**)&p->wscale, (size_t)K * sizeof(float));
