@@ -83,6 +83,7 @@ struct UpdateArgs {
     int dbg;              // ablation mask, tuning only (0 in production)
 };
 hipError_t launch_update(hipStream_t s, const UpdateArgs& a);
+hipError_t launch_update_lds16(hipStream_t s, const UpdateArgs& a);   // 9..16 channels, one workgroup per bin
 
 // Epilogue, overiva.py:192-199.
 //   stats: per-bin sums for projection back: [nsplit][F][K][3] = (Re num, Im num, den)
