@@ -338,6 +338,18 @@ def test_cfg2_mixture_against_oracle(oa):
     assert eY < 5e-5 and eW < max(5e-5, 3 * floor)
 
 
+def test_headline_size_against_oracle(oa):
+    """2048 x 4000 x 8 / 2 (BASELINE.json configs[2]) end to end against the oracle's reference-faithful form
+    (the reference's own arithmetic: complex64 data, float64 activations) for a few iterations."""
+    T, F, M, K = 4000, 2048, 8, 2
+    X = orc.synth_iid(T, F, M, seed=0)
+    Y, W = oa.overiva(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
+    Yr, Wr = orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
+    eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
+    print(f"\n[parity] headline shape iid 3 its vs reference-faithful c64: W err {eW:.2e}  Y err {eY:.2e}")
+    assert eW < TOL and eY < TOL
+
+
 def test_headline_size_properties(oa):
     """2048 bins x 4000 frames x 8 mics / 2 src (BASELINE.json configs[2]): invariants that need no
     oracle, plus a spot check of a few bins against the oracle."""
