@@ -216,6 +216,37 @@ int one_iteration(oiva_plan* p) {
     return stage_update(p, false);
 }
 
+// Capture (stream capture records, it does not execute) and instantiate the two graphs an iterate() call
+// replays: kGraphBatch iterations (amortises the ~10-16 us replay floor, which matters when an iteration is tens
+// of microseconds) and a single iteration for the remainder.  Called from oiva_plan_use_graph when the plan
+// is ready and lazily from oiva_plan_iterate, so that no capture ever lands inside a caller's timed region.
+int build_graphs(oiva_plan* p) {
+    auto capture = [&](int iters, hipGraphExec_t* exec) -> int {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+        int r = OIVA_OK;
+        for (int i = 0; i < iters && r == OIVA_OK; ++i) r = one_iteration(p);
+        hipError_t e = hipStreamEndCapture(p->stream, &graph);
+        if (r) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return r;
+        }
+        HIP_TRY(e);
+        e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIP_TRY(e);
+        return OIVA_OK;
+    };
+    const bool pending = p->wscale_pending;
+    const int raw = p->raw_weights;
+    int rc = OIVA_OK;
+    if (!p->graph_batch_exec) rc = capture(kGraphBatch, &p->graph_batch_exec);
+    if (!rc && !p->graph_exec) rc = capture(1, &p->graph_exec);
+    p->wscale_pending = pending;   // capturing toggled the host-side flags without running anything
+    p->raw_weights = raw;
+    return rc;
+}
+
 int check_ready(oiva_plan* p) {
     NEED(p != nullptr, OIVA_ERR_ARG, "null plan");
     NEED(p->have_x, OIVA_ERR_STATE, "X not set (oiva_plan_set_x_host/_dev)");
@@ -416,33 +447,10 @@ int oiva_plan_iterate(oiva_plan* p, int n) {
     DeviceGuard guard(p->device);
     if (n == 0) return OIVA_OK;
     if (p->use_graph) {
-        // Two captured graphs: kGraphBatch iterations (amortises the ~10-16 us replay floor, which matters when
-        // an iteration is tens of microseconds) and a single iteration for the remainder.
-        auto capture = [&](int iters, hipGraphExec_t* exec) -> int {
-            hipGraph_t graph = nullptr;
-            HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-            int r = OIVA_OK;
-            for (int i = 0; i < iters && r == OIVA_OK; ++i) r = one_iteration(p);
-            hipError_t e = hipStreamEndCapture(p->stream, &graph);
-            if (r) {
-                if (graph) (void)hipGraphDestroy(graph);
-                return r;
-            }
-            HIP_TRY(e);
-            e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            HIP_TRY(e);
-            return OIVA_OK;
-        };
+        if ((rc = build_graphs(p))) return rc;
         int left = n;
-        if (left >= kGraphBatch) {
-            if (!p->graph_batch_exec && (rc = capture(kGraphBatch, &p->graph_batch_exec))) return rc;
-            for (; left >= kGraphBatch; left -= kGraphBatch) HIP_TRY(hipGraphLaunch(p->graph_batch_exec, p->stream));
-        }
-        if (left > 0) {
-            if (!p->graph_exec && (rc = capture(1, &p->graph_exec))) return rc;
-            for (; left > 0; --left) HIP_TRY(hipGraphLaunch(p->graph_exec, p->stream));
-        }
+        for (; left >= kGraphBatch; left -= kGraphBatch) HIP_TRY(hipGraphLaunch(p->graph_batch_exec, p->stream));
+        for (; left > 0; --left) HIP_TRY(hipGraphLaunch(p->graph_exec, p->stream));
         p->wscale_pending = false;
         return OIVA_OK;
     }
@@ -626,6 +634,7 @@ int oiva_plan_use_graph(oiva_plan* p, int enable) {
     DeviceGuard guard(p->device);
     p->use_graph = enable ? 1 : 0;
     if (!enable) return drop_graph(p);
+    if (p->have_x && p->have_cx && p->have_w && p->F == p->F_total) return build_graphs(p);
     return OIVA_OK;
 }
 
