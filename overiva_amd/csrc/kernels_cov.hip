@@ -321,12 +321,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
             xr[2 * j + 1] = v[j].z;
             xi[2 * j + 1] = v[j].w;
         }
-        if (raw & 2) {   // tuning ablation: memory path only, a token amount of arithmetic
-#pragma unroll
-            for (int c = 0; c < M; ++c) acc[0][c] = fmaf(w[0], xr[c] + xi[c], acc[0][c]);
-        } else {
-            accumulate<M, KC, false>(acc, xr, xi, w);
-        }
+        accumulate<M, KC, false>(acc, xr, xi, w);
     };
 
     issue(0, 0);

@@ -269,9 +269,7 @@ template <int M, int KP>
 hipError_t launch_power_one(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int K,
                             const PowGeom& g) {
     dim3 grid(g.nb, g.nsplit, (K + KP - 1) / KP);
-    size_t shmem = (size_t)kWaves * g.tcp * KP * sizeof(float);
-    static const size_t pad = getenv("OIVA_POW_LDS_PAD") ? (size_t)atol(getenv("OIVA_POW_LDS_PAD")) : 0;  // tuning only
-    shmem += pad;
+    const size_t shmem = (size_t)kWaves * g.tcp * KP * sizeof(float);
     hipLaunchKernelGGL((power_kernel<M, KP>), grid, dim3(kBlock), shmem, s, X, What, Ppart, T, F, K, g.tcp);
     return hipGetLastError();
 }

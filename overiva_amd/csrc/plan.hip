@@ -182,9 +182,8 @@ int stage_activation(oiva_plan* p, const float* parts, int nparts) {
     return OIVA_OK;
 }
 int stage_cov(oiva_plan* p) {
-    static const int ablate = getenv("OIVA_COV_ABLATE") ? 2 : 0;   // tuning only
-    HIP_TRY(launch_cov(p->stream, p->X, p->R, p->Plocal /* weights scratch, (T,K) */, p->wscale, p->model,
-                       p->raw_weights | ablate, p->Vpart, p->T, p->F, p->M, p->K, p->cov));
+    HIP_TRY(launch_cov(p->stream, p->X, p->R, p->Plocal /* weights scratch, (T,16) */, p->wscale, p->model,
+                       p->raw_weights, p->Vpart, p->T, p->F, p->M, p->K, p->cov));
     p->wscale_pending = !p->raw_weights;
     return OIVA_OK;
 }

@@ -309,6 +309,7 @@ def test_graph_replay_equals_eager(oa):
             p.set_w(None)
             p.iterate(3)
             p.iterate(2)
+            p.iterate(19)          # 2 batches of 8 iterations + 3 single replays
             outs.append(p.get_w())
     assert np.array_equal(outs[0], outs[1])
 

@@ -13,7 +13,7 @@ out = {}
 for ns in (4, 8, 16, 24, 32, 48, 64):
     p.set_cov_splits(ns)
     out[ns] = [round(p.t_time_stage("weighted_cov", 20) * 1e3, 1) for _ in range(2)]
-print("cov  F=256 splits->us", out, "ablate" if os.environ.get("OIVA_COV_ABLATE") else "")
+print("cov  F=256 splits->us", out, "ablate" if os.environ.get("OIVA_UNUSED") else "")
 out = {}
 for ns in (8, 16, 32, 64, 96, 128, 192):
     p.set_pow_splits(ns)
