@@ -377,6 +377,10 @@ int oiva_plan_set_x_host(oiva_plan* p, const void* X, long long row_pitch_bytes)
     if (!p->X_owned) HIP_TRY(hipMalloc(&p->X_owned, row * p->T));
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemcpy2D(p->X_owned, row, X, pitch, row, p->T, hipMemcpyHostToDevice));
+    if (p->X != p->X_owned) {             // switching from a borrowed array: captured graphs hold its pointer
+        int rc = drop_graph(p);
+        if (rc) return rc;
+    }
     p->X = p->X_owned;
     p->have_x = true;
     p->have_cx = false;
@@ -386,6 +390,12 @@ int oiva_plan_set_x_host(oiva_plan* p, const void* X, long long row_pitch_bytes)
 int oiva_plan_set_x_dev(oiva_plan* p, const void* X_dev) {
     NEED(p && X_dev, OIVA_ERR_ARG, "null argument");
     NEED(((uintptr_t)X_dev & 15) == 0, OIVA_ERR_ARG, "device X must be 16-byte aligned");
+    if (p->X != (const float2*)X_dev) {   // captured graphs hold the old pointer
+        DeviceGuard guard(p->device);
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        int rc = drop_graph(p);
+        if (rc) return rc;
+    }
     p->X = (const float2*)X_dev;
     p->have_x = true;
     p->have_cx = false;
