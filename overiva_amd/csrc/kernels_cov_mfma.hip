@@ -194,26 +194,37 @@ __global__ __launch_bounds__(64, 2) void cov_mfma16_kernel(const float2* __restr
         const int t = t_begin + 4 * g + kf;
         return pcol[(size_t)(t < t_end ? t : T - 1) * frame_stride];
     };
-    float2 xn = fetch(0);
-    for (int g = 0; g < ngroups; ++g) {
-        const int t0 = t_begin + 4 * g;
-        const float2 x = xn;
-        xn = fetch(g + 1 < ngroups ? g + 1 : g);
-        const float live = (t0 + kf < t_end) ? xmask : 0.f;
-        const float xr = x.x * live, xi = x.y * live;
-        // Wt is (T, Kp) with zero padding columns; rows past T-1 in the last group are clamped (uniform)
-        const float* w0 = Wt + (size_t)min(t0, T - 1) * Kp + k0;
-        const float* w1 = Wt + (size_t)min(t0 + 1, T - 1) * Kp + k0;
-        const float* w2 = Wt + (size_t)min(t0 + 2, T - 1) * Kp + k0;
-        const float* w3 = Wt + (size_t)min(t0 + 3, T - 1) * Kp + k0;
+    // kDepth groups of x are in flight per wave (8 bytes per lane and group): with few sources the MFMA work
+    // per group is short and a single outstanding load leaves the wave waiting on HBM
+    constexpr int kDepth = 4;
+    float2 xq[kDepth];
 #pragma unroll
-        for (int kk = 0; kk < KW; ++kk) {
-            float w = 1.f;
-            if constexpr (!UNIT) w = m0 * w0[kk] + m1 * w1[kk] + m2 * w2[kk] + m3 * w3[kk];
-            const float ar = xr * w, ai = xi * w;
-            are[kk] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, xr, are[kk], 0, 0, 0);
-            are[kk] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, xi, are[kk], 0, 0, 0);
-            air[kk] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, xr, air[kk], 0, 0, 0);
+    for (int u = 0; u < kDepth; ++u) xq[u] = fetch(u < ngroups ? u : ngroups - 1);
+    for (int g0 = 0; g0 < ngroups; g0 += kDepth) {
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+            const int g = g0 + u;
+            const float2 x = xq[u];
+            xq[u] = fetch(g + kDepth < ngroups ? g + kDepth : ngroups - 1);
+            if (g < ngroups) {                                         // uniform
+                const int t0 = t_begin + 4 * g;
+                const float live = (t0 + kf < t_end) ? xmask : 0.f;
+                const float xr = x.x * live, xi = x.y * live;
+                // Wt is (T, Kp) with zero padding columns; rows past T-1 in the last group are clamped (uniform)
+                const float* w0 = Wt + (size_t)min(t0, T - 1) * Kp + k0;
+                const float* w1 = Wt + (size_t)min(t0 + 1, T - 1) * Kp + k0;
+                const float* w2 = Wt + (size_t)min(t0 + 2, T - 1) * Kp + k0;
+                const float* w3 = Wt + (size_t)min(t0 + 3, T - 1) * Kp + k0;
+#pragma unroll
+                for (int kk = 0; kk < KW; ++kk) {
+                    float w = 1.f;
+                    if constexpr (!UNIT) w = m0 * w0[kk] + m1 * w1[kk] + m2 * w2[kk] + m3 * w3[kk];
+                    const float ar = xr * w, ai = xi * w;
+                    are[kk] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar, xr, are[kk], 0, 0, 0);
+                    are[kk] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, xi, are[kk], 0, 0, 0);
+                    air[kk] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, xr, air[kk], 0, 0, 0);
+                }
+            }
         }
     }
 
