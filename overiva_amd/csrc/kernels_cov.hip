@@ -17,28 +17,6 @@
 namespace oiva {
 namespace {
 
-template <int M>
-__device__ __forceinline__ void load_x(const float2* __restrict__ p, float (&xr)[M], float (&xi)[M]) {
-    if constexpr (M % 2 == 0) {
-        const float4* p4 = reinterpret_cast<const float4*>(p);
-#pragma unroll
-        for (int i = 0; i < M / 2; ++i) {
-            const float4 v = p4[i];
-            xr[2 * i] = v.x;
-            xi[2 * i] = v.y;
-            xr[2 * i + 1] = v.z;
-            xi[2 * i + 1] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < M; ++i) {
-            const float2 v = p[i];
-            xr[i] = v.x;
-            xi[i] = v.y;
-        }
-    }
-}
-
 // acc[kk][*] += w[kk] * pack(x x^H)
 template <int M, int KC, bool UNIT>
 __device__ __forceinline__ void accumulate(float (&acc)[KC][M * M], const float (&xr)[M], const float (&xi)[M],

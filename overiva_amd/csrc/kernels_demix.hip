@@ -6,32 +6,10 @@
 //   write : Y[t,f,k] = w_{f,k}^H x_{t,f} (* conj z)   reference overiva.py:192-199
 #include <cstdlib>
 
-#include "oiva_internal.h"
+#include "oiva_device.h"
 
 namespace oiva {
 namespace {
-
-template <int M>
-__device__ __forceinline__ void load_x(const float2* __restrict__ p, float (&xr)[M], float (&xi)[M]) {
-    if constexpr (M % 2 == 0) {
-        const float4* p4 = reinterpret_cast<const float4*>(p);
-#pragma unroll
-        for (int i = 0; i < M / 2; ++i) {
-            const float4 v = p4[i];
-            xr[2 * i] = v.x;
-            xi[2 * i] = v.y;
-            xr[2 * i + 1] = v.z;
-            xi[2 * i + 1] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < M; ++i) {
-            const float2 v = p[i];
-            xr[i] = v.x;
-            xi[i] = v.y;
-        }
-    }
-}
 
 // conj(W[f][m][k0+kk]) for the lane's bin; W_hat is (F, M, M) row-major, column k = demixing vector k
 template <int M, int KP>

@@ -48,4 +48,27 @@ __device__ __forceinline__ float activation_weight(float r, float ginv) {
     return 1.f / rn;
 }
 
+// one M-vector (M complex64 = M*8 bytes, 16-byte aligned for even M) into split re/im registers
+template <int M>
+__device__ __forceinline__ void load_x(const float2* __restrict__ p, float (&xr)[M], float (&xi)[M]) {
+    if constexpr (M % 2 == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+        for (int i = 0; i < M / 2; ++i) {
+            const float4 v = p4[i];
+            xr[2 * i] = v.x;
+            xi[2 * i] = v.y;
+            xr[2 * i + 1] = v.z;
+            xi[2 * i + 1] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const float2 v = p[i];
+            xr[i] = v.x;
+            xi[i] = v.y;
+        }
+    }
+}
+
 }  // namespace oiva
