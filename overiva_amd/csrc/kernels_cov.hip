@@ -105,7 +105,6 @@ __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ 
                                                      float* __restrict__ wscale, int model, int raw,
                                                      float* __restrict__ Vpart, int T, int F, int K, int tc) {
     constexpr int NA = M * M;
-    constexpr int NACC = NA * KC;
     __shared__ float lds[kChunk * kLdsStride];
     __shared__ double gscratch[kWaves];
 
