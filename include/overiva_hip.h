@@ -136,7 +136,8 @@ int oiva_plan_set_pow_splits(oiva_plan *p, int nsplit);
 /* Replay the iteration from a captured hipGraph instead of eager launches (default off). */
 int oiva_plan_use_graph(oiva_plan *p, int enable);
 /* Per-bin solve variant: bit 0 = arithmetic (0 float32 (default), 1 float64); bit 1 = lane layout
- * (0 one lane per matrix element (default for <= 8 channels), 1 one lane per matrix row). */
+ * (0 one lane per matrix element / one workgroup per bin (default), 1 one lane per matrix row);
+ * bits 8 and up: ablation mask of the update kernel, used by tools/time_stages.py only (0 in production). */
 int oiva_plan_set_precision(oiva_plan *p, int flags);
 
 /*

@@ -33,9 +33,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# per-file flags (measured choices)
+EXTRA_FLAGS = {}
+
+
 def _compile(src, extra=()):
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
+    extra = tuple(extra) + tuple(EXTRA_FLAGS.get(src, ())) + tuple(os.environ.get("OIVA_EXTRA_" + src.split(".")[0].upper(), "").split())
     if _stale(obj, [path] + HEADERS):
         cmd = [_hipcc(), *FLAGS, *extra, "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
