@@ -63,29 +63,53 @@ def synth_x_device(torch, device, f0, f1):
     return torch.view_as_complex(x)
 
 
-def cpu_baseline():
-    """Reference-faithful NumPy restatement (oracle) on a bounded sample: 128 of the 2048 bins, all
-    4000 frames, 8 mics / 2 src; per-iteration time = (t(3 its) - t(1 it)) / 2 so the prologue
-    cancels; work is linear in bins, so it/s at 2048 bins = it/s on the sample * 128 / 2048."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _time_oracle(fs):
+    """seconds per iteration of the reference-faithful oracle on `fs` bins: (t(3 its) - t(1 it)) / 2, so the
+    prologue (input covariance, allocation) cancels"""
     from oracle import overiva_oracle as orc
 
-    fs = 128
     X = orc.synth_iid(T, fs, M, seed=0)
     t0 = time.perf_counter()
     orc.overiva_faithful(X, n_src=K, n_iter=1, proj_back=False, model=MODEL)
     t1 = time.perf_counter()
     orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=False, model=MODEL)
     t2 = time.perf_counter()
-    per_iter = max(((t2 - t1) - (t1 - t0)) / 2.0, 1e-9)
-    its = (1.0 / per_iter) * fs / F
+    return max(((t2 - t1) - (t1 - t0)) / 2.0, 1e-9)
+
+
+def cpu_baseline():
+    """Reference-faithful NumPy restatement (oracle) on a bounded sample: 128 of the 2048 bins, all 4000
+    frames, 8 mics / 2 src; work is linear in bins, so it/s at 2048 bins = it/s on the sample * 128 / 2048.
+    Timed with the default BLAS threading and, as the reference's own sweep pinned BLAS to one thread
+    (overiva_sim.py:85-91), once more on a smaller sample with one thread."""
+    fs = 128
+    per_iter = _time_oracle(fs)
     threads = os.cpu_count()
+    one = None
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
 
         threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+        fs1 = fs        # same sample: a smaller one would sit in cache and flatter the CPU
+        with threadpool_limits(limits=1):
+            per1 = _time_oracle(fs1)
+        one = {"value": (1.0 / per1) * fs1 / F, "cores": 1,
+               "sample": f"{fs1} of {F} bins, one BLAS thread, {per1:.3f} s per iteration on the sample"}
     except Exception:
         pass
-    return {"value": its, "unit": "iterations/s", "cores": threads, "kind": "port",
+    return {"value": (1.0 / per_iter) * fs / F, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "cpu": _cpu_model(), "host_cpus": os.cpu_count(), "single_thread": one,
             "sample": f"oracle.overiva_faithful (NumPy, complex64 in / float64 r like overiva.py) on {fs} of {F} bins x "
                       f"{T} frames x {M} mics / {K} src, iterations 2-3, scaled by {fs}/{F}; "
                       f"{per_iter:.3f} s per iteration on the sample"}
