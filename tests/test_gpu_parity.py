@@ -385,3 +385,20 @@ def test_headline_size_properties(oa):
     # and the whole run against the oracle on a bin subset is impossible (r couples all bins); instead
     # the activation itself: r from the device's W before the last iteration is covered by
     # test_activation at small sizes; here only its normalisation is checked (above).
+
+
+def test_plain_c_program_runs(oa, tmp_path):
+    """examples/c_abi_demo.c: the C ABI driven from plain C on the GPU"""
+    import os
+    import subprocess
+
+    from conftest import REPO
+
+    exe = tmp_path / "c_abi_demo"
+    pkg = os.path.join(REPO, "overiva_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", "c_abi_demo.c"),
+                        "-L", pkg, "-loveriva_hip", f"-Wl,-rpath,{pkg}", "-lm", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "output energy" in run.stdout

@@ -121,3 +121,18 @@ def test_eig_init_matches_reference_recipe():
     W0 = eig_init(Cx, 2)
     ref = orc.init_demixing(Cx, 2, init_eig=True)[:, :, :2]
     assert np.allclose(W0, ref)
+
+
+def test_plain_c_program_links_against_the_abi(lib, tmp_path):
+    """the header is C (not C++) and the library is usable from a plain-C program"""
+    import subprocess
+
+    exe = tmp_path / "c_abi_demo"
+    pkg = os.path.join(REPO, "overiva_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"),
+                        os.path.join(REPO, "examples", "c_abi_demo.c"), "-L", pkg, "-loveriva_hip",
+                        f"-Wl,-rpath,{pkg}", "-lm", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    if not has_gpu():
+        run = subprocess.run([str(exe)], capture_output=True, text=True)
+        assert run.returncode == 2 and "no GPU" in run.stderr      # loud failure, no CPU path
