@@ -119,7 +119,10 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         // the update kernel adds the nsplit partials of every matrix element one dependent round of loads
         // per 4 splits: beyond 16 splits that costs more there than the fuller grid saves here (measured
         // on a 256-bin shard: update 19.4 -> 15.6 us, covariance unchanged)
-        nsplit = std::min(nsplit, 16);
+        // ... unless 16 splits would leave most of the chip idle (few bins, very long frame axis): then the
+        // streaming pass dominates and up to 64 splits are allowed
+        const int cap = (g.nbg * nz * 16 >= p->n_cu) ? 16 : 64;
+        nsplit = std::min(nsplit, cap);
     }
     g.tc = round_up(ceil_div(p->T, nsplit), 16);
     g.nsplit = ceil_div(p->T, g.tc);
