@@ -231,7 +231,8 @@ def test_auxiva_pca(oa, golden):
         oa.auxiva_pca(X.astype(np.complex128), n_src=K, n_iter=1)
 
 
-@pytest.mark.parametrize("shape", [(96, 5, 11, 3), (80, 3, 9, 9), (72, 6, 13, 1), (64, 4, 16, 5), (50, 7, 7, 7), (90, 19, 5, 2)])
+@pytest.mark.parametrize("shape", [(96, 5, 11, 3), (80, 3, 9, 9), (72, 6, 13, 1), (64, 4, 16, 5), (50, 7, 7, 7), (90, 19, 5, 2),
+                                   (90, 21, 8, 3), (64, 9, 8, 4), (70, 5, 8, 5), (100, 12, 8, 8), (60, 7, 7, 4)])
 def test_odd_shapes_against_oracle(oa, shape):
     """channel counts without a golden fixture (incl. the matrix-core covariance path, 9..16 channels)"""
     T, F, M, K = shape
