@@ -403,3 +403,32 @@ def test_plain_c_program_runs(oa, tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "output energy" in run.stdout
+
+
+def test_two_plans_are_independent_and_no_leak(oa):
+    """distinct plans may be alive and interleaved; repeated create/destroy does not accumulate device memory"""
+    import torch
+
+    Xa = orc.synth_iid(128, 40, 4, seed=11)
+    Xb = orc.synth_iid(96, 33, 3, seed=12)
+    Ya = oa.overiva(Xa, n_src=2, n_iter=4, proj_back=False)
+    Yb = oa.overiva(Xb, n_src=1, n_iter=4, proj_back=False)
+    pa = oa.Plan(128, 40, 4, 2)
+    pb = oa.Plan(96, 33, 3, 1)
+    pa.set_x(Xa); pb.set_x(Xb)
+    pa.covariance(); pb.covariance()
+    pa.set_w(None); pb.set_w(None)
+    for _ in range(4):                      # interleaved iterations on two streams
+        pa.iterate(1)
+        pb.iterate(1)
+    assert np.array_equal(pa.demix(False), Ya) and np.array_equal(pb.demix(False), Yb)
+    pa.close(); pb.close()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        with oa.Plan(512, 256, 8, 2) as p:
+            p.set_x(orc.synth_iid(512, 256, 8, seed=1))
+            p.covariance(); p.set_w(None); p.iterate(2); p.demix(True)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20
