@@ -31,10 +31,10 @@ int main(void) {
     if (oiva_plan_create(&p, 0, T, F, M, K, OIVA_MODEL_LAPLACE, F, NULL) != OIVA_OK ||
         oiva_plan_set_x_host(p, X, 0) != OIVA_OK ||      /* overiva.py:132 */
         oiva_plan_covariance(p) != OIVA_OK ||            /* overiva.py:87 */
-        oiva_plan_set_w(p, NULL) != OIVA_OK ||           /* overiva.py:89-123, identity start */
+        oiva_plan_set_w(p, NULL, 0) != OIVA_OK ||        /* overiva.py:89-123, identity start */
         oiva_plan_iterate(p, 20) != OIVA_OK ||           /* overiva.py:138-190 */
         oiva_plan_demix(p, Y, 0, 1) != OIVA_OK ||        /* overiva.py:192-199 */
-        oiva_plan_get_w(p, W) != OIVA_OK) {              /* overiva.py:201-202 */
+        oiva_plan_get_w(p, W, 0) != OIVA_OK) {           /* overiva.py:201-202 */
         fprintf(stderr, "overiva_hip: %s\n", oiva_last_error());
         return 1;
     }

@@ -36,7 +36,24 @@ extern "C" {
 #define OIVA_MODEL_LAPLACE 0   /* overiva.py:152-153, :161-163 */
 #define OIVA_MODEL_GAUSS 1     /* overiva.py:154-155, :164-167 */
 
+/* Documented limit (the reference has none): at most 16 channels.  Every shape in BASELINE.json and in the
+ * reference's overiva_sim_config.json has <= 16; oiva_plan_create rejects more with OIVA_ERR_ARG. */
 #define OIVA_MAX_CHANNELS 16
+
+/* Arithmetic of a plan (oiva_plan_set_precision).  Device data (X, Y, the W the streaming kernels read) is always
+ * complex64; these bits choose where float64 is used on top of it.
+ *   0                      : float32 everywhere (fp32 matrix-core chains of 8 frames folded into float64).
+ *   OIVA_PREC_UPDATE_F64   : the per-bin algebra (overiva.py:181-190) in float64, W_hat carried in complex128.
+ *   OIVA_PREC_COV_F64      : the weighted covariance (overiva.py:179) accumulated in float64 on the fp64 matrix
+ *                            cores -- the reference's own arithmetic there: its float64 r_inv promotes that
+ *                            product to complex128 even for complex64 input (overiva.py:127-128).
+ *   OIVA_PREC_PRECISE      : both; what overiva() selects for complex128 input.
+ *   OIVA_PREC_UPDATE_ROWS  : lane layout of the per-bin algebra (one lane per matrix row instead of per element). */
+#define OIVA_PREC_FAST 0
+#define OIVA_PREC_UPDATE_F64 1
+#define OIVA_PREC_UPDATE_ROWS 2
+#define OIVA_PREC_COV_F64 4
+#define OIVA_PREC_PRECISE (OIVA_PREC_UPDATE_F64 | OIVA_PREC_COV_F64)
 
 typedef struct oiva_plan oiva_plan;
 
@@ -71,15 +88,17 @@ int oiva_plan_set_x_dev(oiva_plan *p, const void *X_dev);
  * Prologue, step 1: Cx[f] = (1/T) sum_t x x^H  (overiva.py:87).  Must follow set_x.
  */
 int oiva_plan_covariance(oiva_plan *p);
-/* Cx as (F, M, M) complex64 on the host (used by the host-side init_eig path, overiva.py:106-109). */
-int oiva_plan_get_cx(oiva_plan *p, void *Cx_host);
+/* Cx as (F, M, M) complex64 (f64 = 0) or complex128 (f64 != 0) on the host (used by the host-side init_eig
+ * path, overiva.py:106-109, and by auxiva_pca, auxiva_pca.py:71-75). */
+int oiva_plan_get_cx(oiva_plan *p, void *Cx_host, int f64);
 
 /*
  * Prologue, step 2: demixing matrix  (overiva.py:89-123).
- * W0_host: (F, M, K) complex64 or NULL for the identity start (overiva.py:113-114).
- * Builds W_hat = [W | [J; -I]] with J from the orthogonality constraint (overiva.py:96-98,120-123).
+ * W0_host: (F, M, K) complex64 (f64 = 0) or complex128 (f64 != 0), or NULL for the identity start
+ * (overiva.py:113-114).  Builds W_hat = [W | [J; -I]] with J from the orthogonality constraint
+ * (overiva.py:96-98,120-123).
  */
-int oiva_plan_set_w(oiva_plan *p, const void *W0_host);
+int oiva_plan_set_w(oiva_plan *p, const void *W0_host, int f64);
 
 /*
  * n iterations of the loop body overiva.py:138-190 (demix -> activation r -> scale normalisation
@@ -111,9 +130,9 @@ int oiva_plan_update(oiva_plan *p, const void *parts_dev, int nparts);
  * row_pitch_bytes as in set_x_host (0 = dense).  Synchronous.
  */
 int oiva_plan_demix(oiva_plan *p, void *Y_host, long long row_pitch_bytes, int proj_back);
-/* W (F, M, K) complex64 -- the view returned at overiva.py:201-202.  Synchronous.
- * Returns OIVA_ERR_NUMERIC if W holds a non-finite value (W is still copied out). */
-int oiva_plan_get_w(oiva_plan *p, void *W_host);
+/* W (F, M, K) complex64 (f64 = 0) or complex128 (f64 != 0) -- the view returned at overiva.py:201-202.
+ * Synchronous.  Returns OIVA_ERR_NUMERIC if W holds a non-finite value (W is still copied out). */
+int oiva_plan_get_w(oiva_plan *p, void *W_host, int f64);
 
 int oiva_plan_sync(oiva_plan *p);
 
@@ -135,9 +154,8 @@ int oiva_plan_set_cov_splits(oiva_plan *p, int nsplit);
 int oiva_plan_set_pow_splits(oiva_plan *p, int nsplit);
 /* Replay the iteration from a captured hipGraph instead of eager launches (default off). */
 int oiva_plan_use_graph(oiva_plan *p, int enable);
-/* Per-bin solve variant: bit 0 = arithmetic (0 float32 (default), 1 float64); bit 1 = lane layout
- * (0 one lane per matrix element / one workgroup per bin (default), 1 one lane per matrix row);
- * bits 8 and up: ablation mask of the update kernel, used by tools/time_stages.py only (0 in production). */
+/* Arithmetic: an OR of OIVA_PREC_* (default OIVA_PREC_FAST).  Call it before oiva_plan_covariance so that the
+ * prologue runs in the same arithmetic. */
 int oiva_plan_set_precision(oiva_plan *p, int flags);
 
 /*
@@ -147,10 +165,10 @@ int oiva_plan_set_precision(oiva_plan *p, int flags);
 int oiva_test_set_rinv(oiva_plan *p, const float *rinv_host /* (T,K) */);
 int oiva_test_get_rinv(oiva_plan *p, float *rinv_host /* (T,K) */, float *wscale_host /* (K) */);
 int oiva_test_run_weighted_cov(oiva_plan *p);                 /* overiva.py:179 for all K sources */
-int oiva_test_get_v(oiva_plan *p, void *V_host /* (K,F,M,M) complex64 */);
+int oiva_test_get_v(oiva_plan *p, void *V_host /* (K,F,M,M) complex64 | complex128 */, int f64);
 int oiva_test_run_update(oiva_plan *p);                       /* overiva.py:181-190 for s = 0..K-1 */
-int oiva_test_get_what(oiva_plan *p, void *What_host /* (F,M,M) complex64 */);
-int oiva_test_set_what(oiva_plan *p, const void *What_host);
+int oiva_test_get_what(oiva_plan *p, void *What_host /* (F,M,M) complex64 | complex128 */, int f64);
+int oiva_test_set_what(oiva_plan *p, const void *What_host, int f64);
 int oiva_test_run_power(oiva_plan *p, float *p_host /* (T,K) summed over this plan's bins */);
 /* average duration of `reps` back-to-back launches of one stage (0 power, 1 activation, 2 covariance,
  * 3 update) on the plan's current state, HIP events on the plan's stream */

@@ -15,6 +15,9 @@ LIB_PATH = os.path.join(_PKG, "liboveriva_hip.so")
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NUMERIC = 0, -1, -2, -3, -4
 MODEL_IDS = {"laplace": 0, "gauss": 1}
 N_STAGES = 4
+# oiva_plan_set_precision flags (include/overiva_hip.h)
+PREC_FAST, PREC_UPDATE_F64, PREC_UPDATE_ROWS, PREC_COV_F64 = 0, 1, 2, 4
+PREC_PRECISE = PREC_UPDATE_F64 | PREC_COV_F64
 STAGE_NAMES = ("demix_power", "activation", "weighted_cov", "ip_update")
 
 
@@ -38,14 +41,14 @@ SIGNATURES = {
     "oiva_plan_set_x_host": [_vp, _vp, _ll],
     "oiva_plan_set_x_dev": [_vp, _vp],
     "oiva_plan_covariance": [_vp],
-    "oiva_plan_get_cx": [_vp, _vp],
-    "oiva_plan_set_w": [_vp, _vp],
+    "oiva_plan_get_cx": [_vp, _vp, _i],
+    "oiva_plan_set_w": [_vp, _vp, _i],
     "oiva_plan_iterate": [_vp, _i],
     "oiva_plan_power": [_vp],
     "oiva_plan_power_buffer": [_vp, _i, C.POINTER(_vp), C.POINTER(_ll)],
     "oiva_plan_update": [_vp, _vp, _i],
     "oiva_plan_demix": [_vp, _vp, _ll, _i],
-    "oiva_plan_get_w": [_vp, _vp],
+    "oiva_plan_get_w": [_vp, _vp, _i],
     "oiva_plan_sync": [_vp],
     "oiva_plan_iterate_timed": [_vp, _i, _fp, _fp],
     "oiva_plan_get_cov_splits": [_vp, C.POINTER(_i)],
@@ -56,10 +59,10 @@ SIGNATURES = {
     "oiva_test_set_rinv": [_vp, _vp],
     "oiva_test_get_rinv": [_vp, _vp, _vp],
     "oiva_test_run_weighted_cov": [_vp],
-    "oiva_test_get_v": [_vp, _vp],
+    "oiva_test_get_v": [_vp, _vp, _i],
     "oiva_test_run_update": [_vp],
-    "oiva_test_get_what": [_vp, _vp],
-    "oiva_test_set_what": [_vp, _vp],
+    "oiva_test_get_what": [_vp, _vp, _i],
+    "oiva_test_set_what": [_vp, _vp, _i],
     "oiva_test_run_power": [_vp, _vp],
     "oiva_test_time_stage": [_vp, _i, _i, _fp],
 }

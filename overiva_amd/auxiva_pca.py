@@ -28,11 +28,13 @@ def auxiva_pca(X, n_src=None, **kwargs):
     kwargs.pop("proj_back")                                                   # auxiva_pca.py:86
     kwargs.pop("return_filters", None)   # the reference would hand a tuple to projection_back and fail
 
+    precision = _ov.resolve_precision(dtype)
     with Plan(n_frames, n_freq, n_chan, n_src, "laplace", device=_ov.get_device()) as full:
+        full.set_precision(precision)
         full.set_x(X)
         full.covariance()                                                     # auxiva_pca.py:71
         if n_src < n_chan:
-            _, vecs = np.linalg.eigh(full.get_cx().astype(np.complex128))     # auxiva_pca.py:75 (host LAPACK)
+            _, vecs = np.linalg.eigh(full.get_cx(np.complex128))               # auxiva_pca.py:75 (host LAPACK)
             P = np.ascontiguousarray(vecs[:, :, -n_src:])                     # (F, M, K) principal subspace
             full.set_w(P)
             new_X = full.demix(proj_back=False).astype(dtype, copy=False)     # x -> P^H x, auxiva_pca.py:79-81

@@ -1,4 +1,6 @@
-// Weighted spatial covariance pass (the dominant kernel of the iteration).
+// Weighted spatial covariance pass, vector-ALU form: 1..8 channels in float32 (the dominant kernel of the
+// iteration at the headline shape), 1, 2, 3, 5, 6, 7 channels in the float64 accumulation mode (4 and 8
+// channels then run on the fp64 matrix cores, kernels_cov_gram.hip; 9..16 channels: kernels_cov_mfma.hip).
 //
 //   V_k[f] = sum_t rinv[t,k] * x_{t,f} x_{t,f}^H          reference overiva.py:179 (all k in one pass)
 //   Cx[f]  = sum_t x_{t,f} x_{t,f}^H                      reference overiva.py:87   (unit weights)
@@ -9,35 +11,36 @@
 // per frame instead of 4 M^2).  Per-lane partial sums cover ~T/(16*nsplit) frames; the 16 frame
 // phases of a block are combined through LDS (fixed order) and written as one packed partial per
 // (frame split, bin, source).  The per-bin update kernel adds the nsplit partials in fp64.
+
 #include <cstdint>
-#include <cstdlib>
 
 #include "oiva_device.h"
 
 namespace oiva {
 namespace {
 
-// acc[kk][*] += w[kk] * pack(x x^H)
-template <int M, int KC, bool UNIT>
-__device__ __forceinline__ void accumulate(float (&acc)[KC][M * M], const float (&xr)[M], const float (&xi)[M],
-                                           const float (&w)[KC]) {
+// acc[kk][*] += w[kk] * pack(x x^H); ACC = float, or double for the float64 accumulation mode (products of
+// float32 data are then exact, as in the reference's complex128 product at overiva.py:179)
+template <int M, int KC, bool UNIT, typename ACC>
+__device__ __forceinline__ void accumulate(ACC (&acc)[KC][M * M], const ACC (&xr)[M], const ACC (&xi)[M],
+                                           const ACC (&w)[KC]) {
     if constexpr (KC == 1) {
         // one source: scale x once, then 4 FMAs per complex pair
-        float sr[M], si[M];
+        ACC sr[M], si[M];
 #pragma unroll
         for (int c = 0; c < M; ++c) {
             sr[c] = xr[c] * w[0];   // UNIT: w is 1 (live frame) or 0 (clamped tail frame)
             si[c] = xi[c] * w[0];
         }
 #pragma unroll
-        for (int c = 0; c < M; ++c) acc[0][c] = fmaf(sr[c], xr[c], fmaf(si[c], xi[c], acc[0][c]));
+        for (int c = 0; c < M; ++c) acc[0][c] = fma(sr[c], xr[c], fma(si[c], xi[c], acc[0][c]));
         int a = M;
 #pragma unroll
         for (int c = 0; c < M; ++c) {
 #pragma unroll
             for (int d = c + 1; d < M; ++d) {
-                acc[0][a] = fmaf(sr[c], xr[d], fmaf(si[c], xi[d], acc[0][a]));           // Re x_c conj(x_d)
-                acc[0][a + 1] = fmaf(si[c], xr[d], fmaf(-sr[c], xi[d], acc[0][a + 1]));  // Im x_c conj(x_d)
+                acc[0][a] = fma(sr[c], xr[d], fma(si[c], xi[d], acc[0][a]));           // Re x_c conj(x_d)
+                acc[0][a + 1] = fma(si[c], xr[d], fma(-sr[c], xi[d], acc[0][a + 1]));  // Im x_c conj(x_d)
                 a += 2;
             }
         }
@@ -45,21 +48,21 @@ __device__ __forceinline__ void accumulate(float (&acc)[KC][M * M], const float 
         // several sources: form each product once, one FMA per source
 #pragma unroll
         for (int c = 0; c < M; ++c) {
-            const float p = fmaf(xr[c], xr[c], xi[c] * xi[c]);
+            const ACC p = fma(xr[c], xr[c], xi[c] * xi[c]);
 #pragma unroll
-            for (int kk = 0; kk < KC; ++kk) acc[kk][c] = fmaf(w[kk], p, acc[kk][c]);
+            for (int kk = 0; kk < KC; ++kk) acc[kk][c] = fma(w[kk], p, acc[kk][c]);
         }
         int a = M;
 #pragma unroll
         for (int c = 0; c < M; ++c) {
 #pragma unroll
             for (int d = c + 1; d < M; ++d) {
-                const float pre = fmaf(xr[c], xr[d], xi[c] * xi[d]);
-                const float pim = fmaf(xi[c], xr[d], -(xr[c] * xi[d]));
+                const ACC pre = fma(xr[c], xr[d], xi[c] * xi[d]);
+                const ACC pim = fma(xi[c], xr[d], -(xr[c] * xi[d]));
 #pragma unroll
                 for (int kk = 0; kk < KC; ++kk) {
-                    acc[kk][a] = fmaf(w[kk], pre, acc[kk][a]);
-                    acc[kk][a + 1] = fmaf(w[kk], pim, acc[kk][a + 1]);
+                    acc[kk][a] = fma(w[kk], pre, acc[kk][a]);
+                    acc[kk][a + 1] = fma(w[kk], pim, acc[kk][a + 1]);
                 }
                 a += 2;
             }
@@ -74,15 +77,15 @@ constexpr int kLdsStride = kBlock + 1;   // +1: conflict-free transposed read
 // Combine the 16 frame phases of a workgroup (tid = q*16 + b) in rounds of kChunk accumulators through
 // LDS and store one packed partial per (frame split, bin, source):
 //   write lds[a][tid]; thread (bb = tid/16, aa = tid%16) sums lds[aa][qq*16 + bb] over qq (fixed order).
-template <int M, int KC>
-__device__ __forceinline__ void reduce_and_store(const float (&acc)[KC][M * M], float* lds, float* __restrict__ Vpart,
+template <int M, int KC, typename ACC>
+__device__ __forceinline__ void reduce_and_store(const ACC (&acc)[KC][M * M], ACC* lds, ACC* __restrict__ Vpart,
                                                  int F, int K, int k0) {
     constexpr int NA = M * M;
     constexpr int NACC = NA * KC;
     const int tid = threadIdx.x;
     const int bb = tid >> 4, aa = tid & 15;
     const int fo = blockIdx.x * kBinsPerWave + bb;
-    float* out = Vpart + (((size_t)blockIdx.y * F + fo) * K + k0) * NA;
+    ACC* out = Vpart + (((size_t)blockIdx.y * F + fo) * K + k0) * NA;
 #pragma unroll
     for (int r0 = 0; r0 < NACC; r0 += kChunk) {
         __syncthreads();
@@ -91,7 +94,7 @@ __device__ __forceinline__ void reduce_and_store(const float (&acc)[KC][M * M], 
             if (r0 + a < NACC) lds[a * kLdsStride + tid] = acc[(r0 + a) / NA][(r0 + a) % NA];
         }
         __syncthreads();
-        float s = 0.f;
+        ACC s = 0;
 #pragma unroll
         for (int qq = 0; qq < 16; ++qq) s += lds[aa * kLdsStride + qq * 16 + bb];
         const int e = r0 + aa;          // accumulator index = kk*NA + a
@@ -100,12 +103,12 @@ __device__ __forceinline__ void reduce_and_store(const float (&acc)[KC][M * M], 
     }
 }
 
-template <int M, int KC, bool UNIT>
+template <int M, int KC, bool UNIT, typename ACC>
 __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ X, const float* __restrict__ R,
                                                      float* __restrict__ wscale, int model, int raw,
-                                                     float* __restrict__ Vpart, int T, int F, int K, int tc) {
+                                                     ACC* __restrict__ Vpart, int T, int F, int K, int tc) {
     constexpr int NA = M * M;
-    __shared__ float lds[kChunk * kLdsStride];
+    __shared__ ACC lds[kChunk * kLdsStride];
     __shared__ double gscratch[kWaves];
 
     const int tid = threadIdx.x;
@@ -121,29 +124,28 @@ __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ 
     const int nsteps = (t_end - t_begin + 15) >> 4;
 
     // scale normalisation of the activations (overiva.py:158-159): 1/gamma for this pass's sources
-    float ginv[KC];
+    double ginv[KC];
 #pragma unroll
-    for (int kk = 0; kk < KC; ++kk) ginv[kk] = 1.f;
+    for (int kk = 0; kk < KC; ++kk) ginv[kk] = 1.;
     if constexpr (!UNIT) {
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
             const int k = k0 + kk;
-            const float gamma = block_gamma(R, T, K, k < K ? k : K - 1, gscratch);
-            if (!raw) ginv[kk] = 1.f / gamma;
+            const double gamma = block_gamma(R, T, K, k < K ? k : K - 1, gscratch);
+            if (!(raw & 1)) ginv[kk] = 1. / gamma;
             if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && k < K && wscale != nullptr)
-                wscale[k] = model == OIVA_MODEL_LAPLACE ? gamma : sqrtf(gamma);   // overiva.py:163 / :167
+                wscale[k] = model == OIVA_MODEL_LAPLACE ? (float)gamma : (float)sqrt(gamma);   // overiva.py:163 / :167
         }
     }
 
-    float acc[KC][NA];
+    ACC acc[KC][NA];
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
-        for (int a = 0; a < NA; ++a) acc[kk][a] = 0.f;
+        for (int a = 0; a < NA; ++a) acc[kk][a] = 0;
 
     // kCovUnroll steps are loaded before any of them is consumed, so a wave keeps kCovUnroll * 64 * M * 8
-    // bytes in flight (at two waves per SIMD this, not occupancy, is what covers HBM latency).  Frames
-    // past the end of the split are clamped to a legal address and weighted by 0.
+    // bytes in flight.  Frames past the end of the split are clamped to a legal address and weighted by 0.
     const size_t frame_stride = (size_t)F * M;
     const float2* pbase = X + (size_t)fc * M;
     for (int i = 0; i < nsteps; i += kCovUnroll) {
@@ -164,20 +166,31 @@ __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ 
 #pragma unroll
         for (int u = 0; u < kCovUnroll; ++u) {
             const int t = t_begin + q + 16 * (i + u);
-            const float mask = t < t_end ? 1.f : 0.f;
-            float w[KC];
+            const bool live = t < t_end;
+            ACC w[KC], ar[M], ai[M];
 #pragma unroll
             for (int kk = 0; kk < KC; ++kk) {
-                if constexpr (UNIT)
-                    w[kk] = mask;
-                else
-                    w[kk] = activation_weight(rv[u][kk], ginv[kk]) * ((k0 + kk < K) ? mask : 0.f);
+                const bool on = live && (UNIT || k0 + kk < K);
+                if constexpr (UNIT) {
+                    w[kk] = on ? ACC(1) : ACC(0);
+                } else if constexpr (sizeof(ACC) == 8) {
+                    double rn = (double)rv[u][kk] * ginv[kk];
+                    rn = rn < (double)kEpsR ? (double)kEpsR : rn;
+                    w[kk] = on ? 1. / rn : 0.;
+                } else {
+                    w[kk] = on ? activation_weight(rv[u][kk], (float)ginv[kk]) : 0.f;
+                }
             }
-            accumulate<M, KC, UNIT>(acc, xr[u], xi[u], w);
+#pragma unroll
+            for (int c = 0; c < M; ++c) {
+                ar[c] = (ACC)xr[u][c];
+                ai[c] = (ACC)xi[u][c];
+            }
+            accumulate<M, KC, UNIT, ACC>(acc, ar, ai, w);
         }
     }
 
-    reduce_and_store<M, KC>(acc, lds, Vpart, F, K, k0);
+    reduce_and_store<M, KC, ACC>(acc, lds, Vpart, F, K, k0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -276,16 +289,17 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
     // a lane-varying condition gets compiled into branches with the scalar loads inside them)
     const float m0 = ql == 0 ? 1.f : 0.f, m1 = ql == 1 ? 1.f : 0.f, m2 = ql == 2 ? 1.f : 0.f, m3 = ql == 3 ? 1.f : 0.f;
     auto consume = [&](int i, int s) {
-        // weights of the wave's four consecutive frames: uniform addresses -> scalar loads.  R is
-        // allocated with kPhasesPerWave zeroed rows of padding, so reading past frame T-1 is legal.
-        const int tw = t_begin + wave * kPhasesPerWave + 16 * i;
+        // weights of the wave's four consecutive frames: uniform addresses -> scalar loads.  R is allocated
+        // with kPhasesPerWave zeroed rows of padding after frame T-1; waves whose four frames lie wholly past
+        // the end of the tensor (last step of the last split) read those rows, never anything beyond them.
+        const int tw = min(t_begin + wave * kPhasesPerWave + 16 * i, T);
         const float* rp = R + (size_t)tw * K;
         float w[KC];
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
             const int k = k0 + kk < K ? k0 + kk : K - 1;
             const float r = m0 * rp[k] + m1 * rp[K + k] + m2 * rp[2 * K + k] + m3 * rp[3 * K + k];
-            const float live = (tw + ql < t_end && k0 + kk < K) ? 1.f : 0.f;
+            const float live = (t_begin + wave * kPhasesPerWave + 16 * i + ql < t_end && k0 + kk < K) ? 1.f : 0.f;
             w[kk] = activation_weight(r, ginv[kk]) * live;
         }
         float4 v[PIECES];
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
             xr[2 * j + 1] = v[j].z;
             xi[2 * j + 1] = v[j].w;
         }
-        accumulate<M, KC, false>(acc, xr, xi, w);
+        accumulate<M, KC, false, float>(acc, xr, xi, w);
     };
 
     issue(0, 0);
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) {
         const int k = k0 + kk;
-        const float gamma = block_gamma(R, T, K, k < K ? k : K - 1, gscratch);
+        const float gamma = (float)block_gamma(R, T, K, k < K ? k : K - 1, gscratch);
         ginv[kk] = (raw & 1) ? 1.f : 1.f / gamma;
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && k < K && wscale != nullptr)
             wscale[k] = model == OIVA_MODEL_LAPLACE ? gamma : sqrtf(gamma);   // overiva.py:163 / :167
@@ -328,89 +342,99 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
     if (i + 2 < nsteps) { issue(i + 5, 1); consume(i + 2, 2); }
     // drain the DMA queue before the ring is reused as reduction scratch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    reduce_and_store<M, KC>(acc, reinterpret_cast<float*>(ring), Vpart, F, K, k0);
+    reduce_and_store<M, KC, float>(acc, reinterpret_cast<float*>(ring), Vpart, F, K, k0);
 }
 
-using CovKernel = void (*)(const float2*, const float*, float*, int, int, float*, int, int, int, int);
+template <typename ACC>
+using CovKernel = void (*)(const float2*, const float*, float*, int, int, ACC*, int, int, int, int);
 
-// OIVA_COV_DMA=0 selects the register-staged kernel (A/B tuning); default: LDS-DMA ring where available
-inline bool use_dma_path() {
-    static const bool on = !(getenv("OIVA_COV_DMA") && atoi(getenv("OIVA_COV_DMA")) == 0);
-    return on;
-}
-
-// (M, KC, unit weights) -> kernel instantiation, handed to fn together with its KC
-template <int M, typename Fn>
+// (M, KC, unit weights) -> kernel instantiation, handed to fn together with its KC.  Register budget:
+// KC * M^2 accumulators of ACC must stay below ~144 registers.
+template <int M, typename ACC, typename Fn>
 hipError_t dispatch_kc(int kc, bool unit, Fn&& fn) {
-    if (unit) return kc == 1 ? fn((CovKernel)cov_kernel<M, 1, true>, 1) : hipErrorInvalidValue;
-    if constexpr (M == 4 || M == 8) {
-        if (use_dma_path()) {
-            switch (kc) {
-                case 1:
-                    return fn((CovKernel)cov_dma_kernel<M, 1>, 1);
-                case 2:
-                    if constexpr (M * M * 2 <= 144) return fn((CovKernel)cov_dma_kernel<M, 2>, 2);
-                    break;
-                case 4:
-                    if constexpr (M * M * 4 <= 144) return fn((CovKernel)cov_dma_kernel<M, 4>, 4);
-                    break;
-            }
-            return hipErrorInvalidValue;
+    constexpr int kRegs = M * M * (int)(sizeof(ACC) / 4);
+    if (unit) return kc == 1 ? fn((CovKernel<ACC>)cov_kernel<M, 1, true, ACC>, 1) : hipErrorInvalidValue;
+    if constexpr ((M == 4 || M == 8) && sizeof(ACC) == 4) {       // LDS-DMA ring where available
+        switch (kc) {
+            case 1:
+                return fn((CovKernel<ACC>)cov_dma_kernel<M, 1>, 1);
+            case 2:
+                if constexpr (kRegs * 2 <= 144) return fn((CovKernel<ACC>)cov_dma_kernel<M, 2>, 2);
+                break;
+            case 4:
+                if constexpr (kRegs * 4 <= 144) return fn((CovKernel<ACC>)cov_dma_kernel<M, 4>, 4);
+                break;
         }
+        return hipErrorInvalidValue;
     }
     switch (kc) {
         case 1:
-            return fn((CovKernel)cov_kernel<M, 1, false>, 1);
+            return fn((CovKernel<ACC>)cov_kernel<M, 1, false, ACC>, 1);
         case 2:
-            if constexpr (M * M * 2 <= 144) return fn((CovKernel)cov_kernel<M, 2, false>, 2);
+            if constexpr (kRegs * 2 <= 144) return fn((CovKernel<ACC>)cov_kernel<M, 2, false, ACC>, 2);
             break;
         case 4:
-            if constexpr (M * M * 4 <= 144) return fn((CovKernel)cov_kernel<M, 4, false>, 4);
+            if constexpr (kRegs * 4 <= 144) return fn((CovKernel<ACC>)cov_kernel<M, 4, false, ACC>, 4);
             break;
     }
     return hipErrorInvalidValue;
 }
 
-template <typename Fn>
+template <typename ACC, typename Fn>
 hipError_t dispatch_cov(int M, int kc, bool unit, Fn&& fn) {
     switch (M) {
-        case 1: return dispatch_kc<1>(kc, unit, fn);
-        case 2: return dispatch_kc<2>(kc, unit, fn);
-        case 3: return dispatch_kc<3>(kc, unit, fn);
-        case 4: return dispatch_kc<4>(kc, unit, fn);
-        case 5: return dispatch_kc<5>(kc, unit, fn);
-        case 6: return dispatch_kc<6>(kc, unit, fn);
-        case 7: return dispatch_kc<7>(kc, unit, fn);
-        case 8: return dispatch_kc<8>(kc, unit, fn);
+        case 1: return dispatch_kc<1, ACC>(kc, unit, fn);
+        case 2: return dispatch_kc<2, ACC>(kc, unit, fn);
+        case 3: return dispatch_kc<3, ACC>(kc, unit, fn);
+        case 4: return dispatch_kc<4, ACC>(kc, unit, fn);
+        case 5: return dispatch_kc<5, ACC>(kc, unit, fn);
+        case 6: return dispatch_kc<6, ACC>(kc, unit, fn);
+        case 7: return dispatch_kc<7, ACC>(kc, unit, fn);
+        case 8: return dispatch_kc<8, ACC>(kc, unit, fn);
     }
     return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-bool cov_supported(int M) { return M >= 1 && M <= 16; }
+bool cov_supported(int M) { return M >= 1 && M <= OIVA_MAX_CHANNELS; }
 
-// sources handled per pass over X: as many as fit the accumulator budget (KC * M^2 <= 144 registers)
-int cov_sources_per_pass(int M, int K) {
+// sources handled per pass over X
+int cov_sources_per_pass(int M, int K, bool f64) {
+    if (f64 && cov_gram_supported(M)) return cov_gram_sources_per_pass(K);
+    const int regs = M * M * (f64 ? 2 : 1);   // as many as fit the accumulator budget (KC * M^2 <= 144 registers)
     int kc = 1;
-    if (K >= 2 && M * M * 2 <= 144) kc = 2;
-    if (K >= 3 && M * M * 4 <= 144) kc = 4;
+    if (K >= 2 && regs * 2 <= 144) kc = 2;
+    if (K >= 3 && regs * 4 <= 144) kc = 4;
     return kc;
 }
 
 hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
-                      float* Vpart, int T, int F, int M, int K, const CovGeom& g) {
-    if (M > 8) return launch_cov_mfma(s, X, R, Wt, wscale, model, raw, Vpart, T, F, M, K, g.nsplit, g.tc);
-    return dispatch_cov(M, g.kc, R == nullptr, [&](CovKernel kern, int KC) {
-        dim3 grid(g.nbg, g.nsplit, (K + KC - 1) / KC);
-        kern<<<grid, dim3(kBlock), 0, s>>>(X, R, wscale, model, raw, Vpart, T, F, K, g.tc);
+                      void* Vpart, bool f64, int T, int F, int M, int K, const CovGeom& g) {
+    if (M > 8) return launch_cov_mfma(s, X, R, Wt, wscale, model, raw, Vpart, f64, T, F, M, K, g.nsplit, g.tc);
+    if (f64 && cov_gram_supported(M)) return launch_cov_gram(s, X, R, wscale, model, raw, Vpart, T, F, M, K, g);
+    const int kc = R == nullptr ? 1 : g.kc;
+    if (f64)
+        return dispatch_cov<double>(M, kc, R == nullptr, [&](CovKernel<double> kern, int KC) {
+            kern<<<dim3(g.nbg, g.nsplit, (K + KC - 1) / KC), dim3(kBlock), 0, s>>>(X, R, wscale, model, raw,
+                                                                                 static_cast<double*>(Vpart), T, F, K, g.tc);
+            return hipGetLastError();
+        });
+    return dispatch_cov<float>(M, kc, R == nullptr, [&](CovKernel<float> kern, int KC) {
+        kern<<<dim3(g.nbg, g.nsplit, (K + KC - 1) / KC), dim3(kBlock), 0, s>>>(X, R, wscale, model, raw,
+                                                                             static_cast<float*>(Vpart), T, F, K, g.tc);
         return hipGetLastError();
     });
 }
 
 // workgroups of this instantiation that one CU holds at once (registers / LDS limited)
-hipError_t cov_blocks_per_cu(int M, int kc, int* n) {
-    return dispatch_cov(M, kc, false, [&](CovKernel kern, int) {
+hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n) {
+    if (f64 && cov_gram_supported(M)) return cov_gram_blocks_per_cu(kc, n);
+    if (f64)
+        return dispatch_cov<double>(M, kc, false, [&](CovKernel<double> kern, int) {
+            return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, kern, kBlock, 0);
+        });
+    return dispatch_cov<float>(M, kc, false, [&](CovKernel<float> kern, int) {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, kern, kBlock, 0);
     });
 }

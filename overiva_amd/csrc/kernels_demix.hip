@@ -4,8 +4,6 @@
 //           (Y itself is never stored inside the loop: the reference's Y /= gamma at :162/:166 is dead)
 //   stats : per-bin sums for projection back          reference overiva.py:197-198 (pyroomacoustics formula)
 //   write : Y[t,f,k] = w_{f,k}^H x_{t,f} (* conj z)   reference overiva.py:192-199
-#include <cstdlib>
-
 #include "oiva_device.h"
 
 namespace oiva {
@@ -313,7 +311,7 @@ hipError_t launch_power(hipStream_t s, const float2* X, const float2* What, floa
                         const PowGeom& g) {
     // more than 4 sources would take several VALU passes over X (register budget): one MFMA pass instead
     // (measured at 16 channels: 16 sources 770 -> 325 us; 2 sources 191 us VALU vs 332 us MFMA)
-    if (M > 8 && K > 4 && power_mfma_enabled()) return launch_power_mfma(s, X, What, Ppart, T, F, M, K);
+    if (M > 8 && K > 4) return launch_power_mfma(s, X, What, Ppart, T, F, M, K);
 #define CALL(MM)                                                                                        \
     if (g.kp == 1) return launch_power_one<MM, 1>(s, X, What, Ppart, T, F, K, g);                       \
     if (g.kp == 2) return launch_power_one<MM, 2>(s, X, What, Ppart, T, F, K, g);                       \

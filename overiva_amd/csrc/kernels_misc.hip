@@ -27,37 +27,43 @@ __global__ __launch_bounds__(kBlock) void activation_kernel(const float* __restr
     if (e < n && l == 0) R[e] = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(p) : p * inv_f_total;
 }
 
-__global__ __launch_bounds__(kBlock) void sum_parts_kernel(const float* __restrict__ parts, int nparts,
-                                                           float* __restrict__ out, long long n, float scale) {
+template <typename IN>
+__global__ __launch_bounds__(kBlock) void sum_parts_kernel(const IN* __restrict__ parts, int nparts,
+                                                           double* __restrict__ out, long long n, double scale) {
     const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (e >= n) return;
     double s = 0.;
     for (int i = 0; i < nparts; ++i) s += (double)parts[(size_t)i * n + e];
-    out[e] = (float)(s * (double)scale);
+    out[e] = s * scale;
 }
 
-// packed Hermitian (M*M floats) -> full complex M x M
-__global__ __launch_bounds__(kBlock) void unpack_herm_kernel(const float* __restrict__ packed,
-                                                             float2* __restrict__ full, long long nmat, int M,
-                                                             float scale) {
+// packed Hermitian (M*M float64) -> full complex M x M (complex64 or complex128)
+template <typename C2>
+__global__ __launch_bounds__(kBlock) void unpack_herm_kernel(const double* __restrict__ packed, C2* __restrict__ full,
+                                                             long long nmat, int M) {
     const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int NA = M * M;
     if (e >= nmat * NA) return;
     const long long mat = e / NA;
     const int ij = (int)(e - mat * NA);
     const int i = ij / M, j = ij - i * M;
-    const float* p = packed + mat * NA;
-    float2 v;
+    const double* p = packed + mat * NA;
+    double re, im = 0.;
     if (i == j) {
-        v = make_float2(p[i], 0.f);
+        re = p[i];
     } else if (i < j) {
         const int o = herm_pair_index(M, i, j);
-        v = make_float2(p[o], p[o + 1]);
+        re = p[o];
+        im = p[o + 1];
     } else {
         const int o = herm_pair_index(M, j, i);
-        v = make_float2(p[o], -p[o + 1]);
+        re = p[o];
+        im = -p[o + 1];
     }
-    full[e] = make_float2(v.x * scale, v.y * scale);
+    C2 v;
+    v.x = re;
+    v.y = im;
+    full[e] = v;
 }
 
 }  // namespace
@@ -71,16 +77,22 @@ hipError_t launch_activation(hipStream_t s, const float* parts, int nparts, floa
     return hipGetLastError();
 }
 
-hipError_t launch_sum_parts(hipStream_t s, const float* parts, int nparts, float* out, long long n, float scale) {
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, parts, nparts,
-                       out, n, scale);
+hipError_t launch_sum_parts(hipStream_t s, const void* parts, bool f64, int nparts, double* out, long long n, double scale) {
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    if (f64)
+        hipLaunchKernelGGL(sum_parts_kernel<double>, grid, dim3(kBlock), 0, s, static_cast<const double*>(parts), nparts, out, n, scale);
+    else
+        hipLaunchKernelGGL(sum_parts_kernel<float>, grid, dim3(kBlock), 0, s, static_cast<const float*>(parts), nparts, out, n, scale);
     return hipGetLastError();
 }
 
-hipError_t launch_unpack_herm(hipStream_t s, const float* packed, float2* full, long long nmat, int M, float scale) {
+hipError_t launch_unpack_herm(hipStream_t s, const double* packed, void* full, bool out_f64, long long nmat, int M) {
     const long long n = nmat * M * M;
-    hipLaunchKernelGGL(unpack_herm_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, packed, full,
-                       nmat, M, scale);
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    if (out_f64)
+        hipLaunchKernelGGL(unpack_herm_kernel<double2>, grid, dim3(kBlock), 0, s, packed, static_cast<double2*>(full), nmat, M);
+    else
+        hipLaunchKernelGGL(unpack_herm_kernel<float2>, grid, dim3(kBlock), 0, s, packed, static_cast<float2*>(full), nmat, M);
     return hipGetLastError();
 }
 

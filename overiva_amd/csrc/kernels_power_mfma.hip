@@ -6,8 +6,6 @@
 //   i.e. 4 MFMAs per channel chunk, 16 per bin and 16 frames.  |y|^2 is accumulated over the bins of a batch
 //   in the accumulator layout (lane = frame, 4 sources per lane), so nothing is exchanged between lanes and Y is
 //   never stored.  The VALU kernel needs K/4 passes over X at K = 16 (register budget); this one reads X once.
-#include <cstdlib>
-
 #include "oiva_device.h"
 
 namespace oiva {
@@ -81,11 +79,6 @@ __global__ __launch_bounds__(kBlock) void power_mfma_kernel(const float2* __rest
 }
 
 }  // namespace
-
-bool power_mfma_enabled() {
-    static const bool off = getenv("OIVA_POW_VALU") != nullptr;   // A/B tuning switch
-    return !off;
-}
 
 hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K) {
     dim3 grid((F + kBinsPerBatch - 1) / kBinsPerBatch, (T + 16 * kWaves - 1) / (16 * kWaves));

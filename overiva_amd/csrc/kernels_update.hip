@@ -145,8 +145,9 @@ __global__ __launch_bounds__(kBlock) void update_kernel(UpdateArgs a) {
     for (int m = 0; m < SG; ++m) {
         B[m] = {R(m == i ? 1 : 0), R(0)};
         if (m < M && row_ok) {
-            const float2 v = a.What[((size_t)f * M + m) * M + i];
-            B[m] = {R(v.x), R(-v.y)};
+            R vr, vi;
+            load_what<R>(a, ((size_t)f * M + m) * M + i, vr, vi);
+            B[m] = {vr, -vi};
         }
     }
     if (a.wscale != nullptr && i < K) {  // overiva.py:163 / :167
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void update_kernel(UpdateArgs a) {
             int off;
             float sgn;
             herm_offsets(M, i, j, off, sgn);
-            const float* p = a.Cx + (size_t)f * NA + off;
+            const double* p = a.Cx + (size_t)f * NA + off;
             C[j].re = R(p[0]);
             if (sgn != 0.f) C[j].im = R(sgn * p[1]);
         }
@@ -205,9 +206,9 @@ __global__ __launch_bounds__(kBlock) void update_kernel(UpdateArgs a) {
                     herm_offsets(M, i, j, off, sgn);
                     double sr = 0., si = 0.;
                     for (int sp = 0; sp < a.nsplit; ++sp) {
-                        const float* p = a.Vpart + (((size_t)sp * a.F + f) * K + s) * NA + off;
-                        sr += (double)p[0];
-                        if (sgn != 0.f) si += (double)p[1];
+                        const size_t idx = (((size_t)sp * a.F + f) * K + s) * NA + off;
+                        sr += load_vpart(a.Vpart, a.vpart_f64, idx);
+                        if (sgn != 0.f) si += load_vpart(a.Vpart, a.vpart_f64, idx + 1);
                     }
                     Vr[j].re = R(sr) * invT;
                     Vr[j].im = R(si) * R(sgn) * invT;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void update_kernel(UpdateArgs a) {
     if (fvalid && row_ok) {
 #pragma unroll
         for (int m = 0; m < SG; ++m) {
-            if (m < M) a.What[((size_t)f * M + m) * M + i] = make_float2((float)B[m].re, (float)(-B[m].im));
+            if (m < M) store_what<R>(a, ((size_t)f * M + m) * M + i, B[m].re, -B[m].im);
         }
     }
 }
@@ -486,8 +487,9 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
     // B[i][j] = (W_hat^H)[i][j] = conj(W_hat[j][i]); identity outside M x M
     Cx<R> B = eye;
     if (in) {
-        const float2 v = a.What[((size_t)f * M + j) * M + i];
-        B = {R(v.x), R(-v.y)};
+        R vr, vi;
+        load_what<R>(a, ((size_t)f * M + j) * M + i, vr, vi);
+        B = {vr, -vi};
     }
     if (a.wscale != nullptr && i < K) {  // overiva.py:163 / :167
         const R s = R(1) / R(a.wscale[i]);
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
     if (in) herm_offsets(M, i, j, off, sgn);
     Cx<R> C = zero;
     if (in) {
-        const float* p = a.Cx + (size_t)f * NA + off;
+        const double* p = a.Cx + (size_t)f * NA + off;
         C.re = R(p[0]);
         if (sgn != 0.f) C.im = R(sgn * p[1]);
     }
@@ -507,21 +509,20 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
     Cx<R> Tm = zero;
     if (K < M) Tm = sq.matmul(B, C, M);
 
-    int nsrc = a.init_only ? 0 : K;
-    if (a.dbg & 1) nsrc = 0;          // ablation: loads/stores only
+    const int nsrc = a.init_only ? 0 : K;
     const R invT = R(1) / R(a.T);
     // V_s[i][j] = (1/T) * fixed-order fp64 sum of the frame-split partials (reduction tail of overiva.py:179)
     auto load_v = [&](int s) {
         Cx<R> V = zero;
         if (in) {
             double sr = 0., si = 0.;
-            const float* p = a.Vpart + ((size_t)f * K + s) * NA + off;
+            const size_t base = ((size_t)f * K + s) * NA + off;
             const size_t stride = (size_t)a.F * K * NA;
             const bool has_im = sgn != 0.f;
 #pragma unroll 4
             for (int sp = 0; sp < a.nsplit; ++sp) {
-                sr += (double)p[sp * stride];
-                if (has_im) si += (double)p[sp * stride + 1];
+                sr += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride);
+                if (has_im) si += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride + 1);
             }
             V.re = R(sr) * invT;
             V.im = R(si) * R(sgn) * invT;
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
             Cx<R> rhs = {R(i == s ? 1 : 0), R(0)};
             int perm[MP];
             Cx<R> piv = {R(1), R(0)};
-            sq.gauss_jordan(A, rhs, (a.dbg & 2) ? 1 : MP, false, perm, piv);
+            sq.gauss_jordan(A, rhs, MP, false, perm, piv);
             const Cx<R> q = cmul(rhs, cinv(piv));  // = w[c] on the row that pivoted column c
 #pragma unroll
             for (int c = 0; c < MP; ++c) {
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
             wj.im *= sc;
             if (i == s) B = {wj.re, -wj.im};
         }
-        if (K < M && !(a.dbg & 4)) {
+        if (K < M) {
             if (solve) {
                 // row s of W^H Cx = sum_m conj(w_m) Cx[m][:]
                 Cx<R> t = cmul(Cx<R>{wi.re, -wi.im}, C);
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
             }
         }
     }
-    if (fvalid && in) a.What[((size_t)f * M + j) * M + i] = make_float2((float)B.re, (float)(-B.im));
+    if (fvalid && in) store_what<R>(a, ((size_t)f * M + j) * M + i, B.re, -B.im);
 }
 
 template <int MP, int MT, int KT>
@@ -604,7 +605,7 @@ hipError_t launch_sq_one(hipStream_t s, const UpdateArgs& a) {
 // determined), generic otherwise
 template <int MP>
 hipError_t launch_sq(hipStream_t s, const UpdateArgs& a) {
-    if (a.M == MP && !(a.dbg & 8)) {
+    if (a.M == MP) {
         if (a.K == 2 && MP >= 2) return launch_sq_one<MP, MP, 2>(s, a);
         if (a.K == MP) return launch_sq_one<MP, MP, MP>(s, a);
         if (a.K == 1) return launch_sq_one<MP, MP, 1>(s, a);

@@ -136,8 +136,9 @@ __global__ __launch_bounds__(kBlock) void update_lds16_kernel(UpdateArgs a) {
     // B[i][j] = (W_hat^H)[i][j] = conj(W_hat[j][i]); identity outside M x M
     C2<R> B = eye;
     if (in) {
-        const float2 v = a.What[((size_t)f * M + j) * M + i];
-        B = {R(v.x), R(-v.y)};
+        R vr, vi;
+        load_what<R>(a, ((size_t)f * M + j) * M + i, vr, vi);
+        B = {vr, -vi};
     }
     if (a.wscale != nullptr && i < K) {   // overiva.py:163 / :167
         const R sc = R(1) / R(a.wscale[i]);
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void update_lds16_kernel(UpdateArgs a) {
     if (in) herm_off(M, i, j, off, sgn);
     C2<R> C = zero;
     if (in) {
-        const float* p = a.Cx + (size_t)f * NA + off;
+        const double* p = a.Cx + (size_t)f * NA + off;
         C.re = R(p[0]);
         if (sgn != 0.f) C.im = R(sgn * p[1]);
     }
@@ -167,12 +168,12 @@ __global__ __launch_bounds__(kBlock) void update_lds16_kernel(UpdateArgs a) {
             C2<R> V = zero;
             if (in) {
                 double sr = 0., si = 0.;
-                const float* p = a.Vpart + ((size_t)f * K + src) * NA + off;
+                const size_t base = ((size_t)f * K + src) * NA + off;
                 const size_t stride = (size_t)a.F * K * NA;
 #pragma unroll 4
                 for (int sp = 0; sp < a.nsplit; ++sp) {
-                    sr += (double)p[sp * stride];
-                    if (sgn != 0.f) si += (double)p[sp * stride + 1];
+                    sr += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride);
+                    if (sgn != 0.f) si += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride + 1);
                 }
                 V.re = R(sr) * invT;
                 V.im = R(si) * R(sgn) * invT;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void update_lds16_kernel(UpdateArgs a) {
             if (i >= K && i < M && j < K) B = cconj(s.mB[j][i]);
         }
     }
-    if (in) a.What[((size_t)f * M + j) * M + i] = make_float2((float)B.re, (float)(-B.im));
+    if (in) store_what<R>(a, ((size_t)f * M + j) * M + i, B.re, -B.im);
 }
 
 }  // namespace

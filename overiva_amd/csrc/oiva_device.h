@@ -24,7 +24,7 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // gamma_k = mean_t R[t,k]  (reference overiva.py:158), computed by a whole workgroup in a fixed order so
 // that every workgroup of every kernel obtains the same bits.  R is (T, K), a few KB, L2 resident.
 // Loads are issued 16 at a time so the cost is a couple of memory round trips, not T/256 of them.
-__device__ __forceinline__ float block_gamma(const float* __restrict__ R, int T, int K, int k, double* scratch) {
+__device__ __forceinline__ double block_gamma(const float* __restrict__ R, int T, int K, int k, double* scratch) {
     constexpr int kBatch = 16;
     double s = 0.;
     for (int t0 = threadIdx.x; t0 < T; t0 += kBlock * kBatch) {
@@ -38,7 +38,7 @@ __device__ __forceinline__ float block_gamma(const float* __restrict__ R, int T,
         for (int u = 0; u < kBatch; ++u) s += (t0 + u * kBlock < T) ? (double)v[u] : 0.;
     }
     s = block_sum(s, scratch);
-    return (float)(s / (double)T);
+    return s / (double)T;
 }
 
 // 1 / max(r / gamma, eps)   (reference overiva.py:159, :170-173) with ginv = 1 / gamma
@@ -70,5 +70,29 @@ __device__ __forceinline__ void load_x(const float2* __restrict__ p, float (&xr)
         }
     }
 }
+
+// ---- fp32 / fp64 matrix-core tile of shape 16x16x4 (A, B: one value per lane; C/D: 4 values per lane) ----
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+template <typename REAL>
+struct Mfma;
+template <>
+struct Mfma<float> {
+    using acc_t = f32x4;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);     // exact fp32 fmaf chain over the 4 k
+    }
+    // C/D layout: lane l, register r -> row; the column is l & 15
+    static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+template <>
+struct Mfma<double> {
+    using acc_t = f64x4;
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }   // NOT the fp32 map
+};
 
 }  // namespace oiva

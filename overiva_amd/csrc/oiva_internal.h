@@ -42,15 +42,24 @@ constexpr int kPowMaxFrames = 512;
 //   X (T,F,M) c64; R (T,K) f32 activations r (unnormalised) or nullptr for unit weights (then K must be 1)
 //   weights: w[t,k] = 1 / max(R[t,k] / gamma_k, eps), gamma_k = mean_t R (overiva.py:158-173); with raw != 0
 //   gamma is taken as 1.  wscale (K): out, gamma (laplace) | sqrt(gamma) (gauss), written by one workgroup.
-//   Vpart [nsplit][F][K][M*M] packed partial sums (NOT divided by T)
+//   Vpart [nsplit][F][K][M*M] packed partial sums (NOT divided by T), float32 or (f64 != 0) float64
+//   f64: accumulate in float64 (the reference's arithmetic: its float64 r_inv promotes overiva.py:179 to complex128)
 hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
-                      float* Vpart, int T, int F, int M, int K, const CovGeom& g);
-// matrix-core variant for 9..16 channels (grid = F bins x nsplit, tc frames per split, tc even)
-//   Wt (T,K): scratch for the final weights (written by a small pre-pass)
+                      void* Vpart, bool f64, int T, int F, int M, int K, const CovGeom& g);
+// float64 real-Gram kernel on the fp64 matrix cores for 4 and 8 channels (kernels_cov_gram.hip); tc multiple of 4,
+// Vpart float64
+bool cov_gram_supported(int M);
+int cov_gram_sources_per_pass(int K);
+int cov_gram_max_frames();   // frames per workgroup the kernel can take
+hipError_t launch_cov_gram(hipStream_t s, const float2* X, const float* R, float* wscale, int model, int raw, void* Vpart,
+                           int T, int F, int M, int K, const CovGeom& g);
+hipError_t cov_gram_blocks_per_cu(int kc, int* n);
+// planar matrix-core kernel for 9..16 channels (grid = F bins x nsplit, tc frames per split, tc multiple of 4)
+//   Wt (T,16): scratch for the final weights (written by a small pre-pass)
 hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
-                           float* Vpart, int T, int F, int M, int K, int nsplit, int tc);
-int cov_sources_per_pass(int M, int K);
-hipError_t cov_blocks_per_cu(int M, int kc, int* n);
+                           void* Vpart, bool f64, int T, int F, int M, int K, int nsplit, int tc);
+int cov_sources_per_pass(int M, int K, bool f64);
+hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n);
 bool cov_supported(int M);
 
 // Demix + source power, overiva.py:140 + the norms at :153/:155.
@@ -59,29 +68,52 @@ hipError_t launch_power(hipStream_t s, const float2* X, const float2* What, floa
                         int K, const PowGeom& g);
 // matrix-core variant for 9..16 channels (same Ppart layout, one pass over X for all sources)
 hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K);
-bool power_mfma_enabled();
 int pow_sources_per_pass(int M, int K);
 hipError_t pow_blocks_per_cu(int M, int kp, int tcp, int* n);
 
 // Source activation, overiva.py:152-155: parts [nparts][T][K] -> R (T,K) = 2 sqrt(p) | p / F_total.
 hipError_t launch_activation(hipStream_t s, const float* parts, int nparts, float* R, int T, int K, int model,
                              int F_total);
-// sum of partial buffers: out[e] = sum_i parts[i][e]
-hipError_t launch_sum_parts(hipStream_t s, const float* parts, int nparts, float* out, long long n, float scale);
+// fixed-order float64 sum of partial buffers (float32, or float64 when f64): out[e] = scale * sum_i parts[i][e]
+hipError_t launch_sum_parts(hipStream_t s, const void* parts, bool f64, int nparts, double* out, long long n, double scale);
 
 // Per-bin sequential update, overiva.py:181-190 (+ :161-167 W scaling, + :96-98 J init when init_only).
 struct UpdateArgs {
-    float2* What;         // (F,M,M) in/out
-    const float* Cx;      // [F][M*M] packed, already divided by T
-    const float* Vpart;   // [nsplit][F][K][M*M] packed partial sums
+    float2* What;         // (F,M,M) in/out (complex64: what the streaming kernels read)
+    double2* What64;      // (F,M,M) complex128 copy carried between iterations by the float64 variants (or nullptr)
+    const double* Cx;     // [F][M*M] packed, already divided by T
+    const void* Vpart;    // [nsplit][F][K][M*M] packed partial sums, float32 or (vpart_f64) float64
+    int vpart_f64;
     const float* wscale;  // (K) or nullptr
     int nsplit;
     int T, F, M, K;
     int init_only;        // 1: only (re)compute J from W and Cx
     int use_double;       // per-bin algebra in fp64
     int layout;           // 0: one lane per matrix element (M <= 8), 1: one lane per matrix row
-    int dbg;              // ablation mask, tuning only (0 in production)
 };
+// W_hat element idx: the float64 variants keep their own complex128 copy so that nothing is rounded to
+// float32 between iterations; the complex64 array is always written (the streaming kernels read it)
+template <typename R>
+__device__ __forceinline__ void load_what(const UpdateArgs& a, size_t idx, R& re, R& im) {
+    if (sizeof(R) == 8 && a.What64 != nullptr) {
+        const double2 v = a.What64[idx];
+        re = (R)v.x;
+        im = (R)v.y;
+    } else {
+        const float2 v = a.What[idx];
+        re = (R)v.x;
+        im = (R)v.y;
+    }
+}
+template <typename R>
+__device__ __forceinline__ void store_what(const UpdateArgs& a, size_t idx, R re, R im) {
+    a.What[idx] = make_float2((float)re, (float)im);
+    if (sizeof(R) == 8 && a.What64 != nullptr) a.What64[idx] = make_double2((double)re, (double)im);
+}
+// one packed partial as float64 whatever its storage type
+__device__ __forceinline__ double load_vpart(const void* base, int f64, size_t idx) {
+    return f64 ? static_cast<const double*>(base)[idx] : (double)static_cast<const float*>(base)[idx];
+}
 hipError_t launch_update(hipStream_t s, const UpdateArgs& a);
 hipError_t launch_update_lds16(hipStream_t s, const UpdateArgs& a);   // 9..16 channels, one workgroup per bin
 
@@ -92,7 +124,7 @@ hipError_t launch_demix_stats(hipStream_t s, const float2* X, const float2* What
 //   write Y (T,F,K) c64, scaled by conj(z) when Spart != nullptr
 hipError_t launch_demix_write(hipStream_t s, const float2* X, const float2* What, const float* Spart, int nsplit,
                               float2* Y, int T, int F, int M, int K);
-// unpack packed Hermitian [F][K?][M*M] -> full complex (F,M,M) with scale
-hipError_t launch_unpack_herm(hipStream_t s, const float* packed, float2* full, long long nmat, int M, float scale);
+// unpack packed Hermitian float64 [nmat][M*M] -> full complex nmat x (M,M): complex64, or complex128 when out_f64
+hipError_t launch_unpack_herm(hipStream_t s, const double* packed, void* full, bool out_f64, long long nmat, int M);
 
 }  // namespace oiva

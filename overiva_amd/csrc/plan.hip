@@ -47,9 +47,11 @@ struct oiva_plan {
 
     const float2* X = nullptr;  // (T,F,M)
     float2* X_owned = nullptr;
-    float2* What = nullptr;     // (F,M,M)
-    float* Cx = nullptr;        // [F][M*M] packed, / T
-    float* Vpart = nullptr;     // [nsplit][F][K][M*M]
+    float2* What = nullptr;     // (F,M,M) complex64: what the streaming kernels read
+    double2* What64 = nullptr;  // (F,M,M) complex128: carried between iterations by the float64 update
+    bool what64_valid = false;
+    double* Cx = nullptr;       // [F][M*M] packed, / T
+    void* Vpart = nullptr;      // [nsplit][F][K][M*M] packed partial sums, float32 or float64 (cov_f64())
     float* Ppart = nullptr;     // [nb (or more, zero padded)][T][K]
     int ppart_alloc = 0;
     float* Plocal = nullptr;    // (T,K)
@@ -57,7 +59,8 @@ struct oiva_plan {
     float* wscale = nullptr;    // (K)
     float* Spart = nullptr;     // [nsplit][F][K][3]
     float2* Y = nullptr;        // (T,F,K), allocated on first demix
-    float2* scratch_c = nullptr;  // max(F*M*M, K*F*M*M) complex, for getters
+    double2* scratch_c = nullptr;  // K*F*M*M complex128, for getters
+    double* scratch_p = nullptr;   // K*F*M*M packed float64, for getters
 
     CovGeom cov{};
     PowGeom pw{};
@@ -67,7 +70,9 @@ struct oiva_plan {
     bool have_x = false, have_cx = false, have_w = false;
     bool wscale_pending = false;  // wscale computed (by the covariance pass), update not yet applied
     int raw_weights = 0;          // test hook: R holds final 1/weights, no gamma normalisation
-    int use_double = 0;
+    int prec = 0;                 // OIVA_PREC_* bits (oiva_plan_set_precision)
+    bool upd_f64() const { return prec & OIVA_PREC_UPDATE_F64; }
+    bool cov_f64() const { return prec & OIVA_PREC_COV_F64; }
     int use_graph = 0;
     hipGraphExec_t graph_exec = nullptr;        // one iteration
     hipGraphExec_t graph_batch_exec = nullptr;  // kGraphBatch iterations
@@ -78,21 +83,22 @@ namespace {
 
 // Frame splits are chosen so that the grid is a whole number of "rounds" of what the chip holds at
 // once (CUs x resident workgroups per CU): a grid of 1.5 rounds runs as long as one of 2.
-int pick_splits(int capacity, int blocks_per_split, int T, int quantum, int min_frames, int max_rounds) {
-    (void)quantum;
-    int ns = std::max(1, (max_rounds * capacity) / std::max(1, blocks_per_split));
+int pick_splits(int capacity, int blocks_per_split, int T, int min_frames) {
+    int ns = std::max(1, capacity / std::max(1, blocks_per_split));
     ns = std::min(ns, std::max(1, T / std::max(1, min_frames)));   // every split keeps >= min_frames frames
     return ns;
 }
 
 void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     CovGeom g;
-    g.nbg = ceil_div(p->F, kBinsPerWave);
-    g.kc = cov_sources_per_pass(p->M, p->K);
+    const bool gram = p->cov_f64() && cov_gram_supported(p->M);
+    // workgroups along the bin axis: 16 tiles of 16 floats (matrix-core kernel, 4 / 8 channels) or 16 bins
+    g.nbg = gram ? ceil_div(ceil_div(p->F * p->M * 2, 16), 16) : ceil_div(p->F, kBinsPerWave);
+    g.kc = cov_sources_per_pass(p->M, p->K, p->cov_f64());
     const int nz = ceil_div(p->K, g.kc);
     int nsplit = nsplit_req;
     if (p->M > 8) {
-        // matrix-core path: one workgroup per (bin, split); splits bound the length of the fp32
+        // planar matrix-core path: one wave per (bin, split); splits bound the length of the fp32
         // accumulation chain (<= 512 frames) and keep >= 2 waves per SIMD when there are few bins
         if (nsplit <= 0) {
             nsplit = ceil_div(p->T, 512);
@@ -104,12 +110,14 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         p->cov = g;
         return;
     }
+    const int quantum = gram ? 4 : 16;      // frames per step of a workgroup
     if (nsplit <= 0) {
         int bpc = 2;
-        if (cov_blocks_per_cu(p->M, g.kc, &bpc) != hipSuccess || bpc < 1) bpc = 2;
-        // one round: every workgroup pays a fixed ~5 us (gamma prologue, LDS reduction epilogue), so
-        // fewer, longer workgroups win as long as the chip is full (measured 4 vs 8 vs 16 splits)
-        nsplit = pick_splits(p->n_cu * bpc, g.nbg * nz, p->T, 16, 128, 1);
+        if (cov_blocks_per_cu(p->M, g.kc, p->cov_f64(), &bpc) != hipSuccess || bpc < 1) bpc = 2;
+        // one round: the grid is what the chip holds at once (CUs x resident workgroups); every workgroup pays a
+        // fixed cost (gamma prologue, ring fill, epilogue), so fewer, longer workgroups win as long as the chip
+        // is full, and 1.5 rounds run as long as 2
+        nsplit = pick_splits(p->n_cu * bpc, g.nbg * nz, p->T, 128);
         // the update kernel adds the nsplit partials of every matrix element one dependent round of loads
         // per 4 splits: beyond 16 splits that costs more there than the fuller grid saves here (measured
         // on a 256-bin shard: update 19.4 -> 15.6 us, covariance unchanged)
@@ -118,7 +126,8 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         const int cap = (g.nbg * nz * 16 >= p->n_cu) ? 16 : 64;
         nsplit = std::min(nsplit, cap);
     }
-    g.tc = round_up(ceil_div(p->T, nsplit), 16);
+    if (gram) nsplit = std::max(nsplit, ceil_div(p->T, cov_gram_max_frames() - 4));   // the kernel's weight table
+    g.tc = round_up(ceil_div(p->T, nsplit), quantum);
     g.nsplit = ceil_div(p->T, g.tc);
     p->cov = g;
 }
@@ -134,7 +143,7 @@ void choose_pow_geom(oiva_plan* p, int nsplit_req) {
         // workgroups run 3x slower than 768 on the headline shape), fewer expose HBM latency
         // and at least 64 frames (16 steps per wave) per workgroup: each one loads its W first (measured on a
         // 256-bin shard: 62 splits 13.5 us, 167 splits 15.9 us)
-        nsplit = pick_splits(p->n_cu * 3, g.nb * nz, p->T, 4, 64, 1);
+        nsplit = pick_splits(p->n_cu * 3, g.nb * nz, p->T, 64);
     }
     int tcp = round_up(ceil_div(p->T, nsplit), 4);
     tcp = std::min(std::max(tcp, 4), kPowMaxFrames);
@@ -163,7 +172,7 @@ int ensure_vpart(oiva_plan* p) {
         p->Vpart = nullptr;
         if (p->Spart) HIP_TRY(hipFree(p->Spart));
         p->Spart = nullptr;
-        HIP_TRY(hipMalloc(&p->Vpart, vpart_floats(p, p->cov.nsplit) * sizeof(float)));
+        HIP_TRY(hipMalloc(&p->Vpart, vpart_floats(p, p->cov.nsplit) * sizeof(double)));   // either element type
         HIP_TRY(hipMalloc(&p->Spart, (size_t)p->cov.nsplit * p->F * p->K * 3 * sizeof(float)));
         p->vpart_splits_alloc = p->cov.nsplit;
     }
@@ -182,15 +191,17 @@ int stage_activation(oiva_plan* p, const float* parts, int nparts) {
 }
 int stage_cov(oiva_plan* p) {
     HIP_TRY(launch_cov(p->stream, p->X, p->R, p->Plocal /* weights scratch, (T,16) */, p->wscale, p->model,
-                       p->raw_weights, p->Vpart, p->T, p->F, p->M, p->K, p->cov));
+                       p->raw_weights, p->Vpart, p->cov_f64(), p->T, p->F, p->M, p->K, p->cov));
     p->wscale_pending = !p->raw_weights;
     return OIVA_OK;
 }
 int stage_update(oiva_plan* p, bool init_only) {
     UpdateArgs a;
     a.What = p->What;
+    a.What64 = p->upd_f64() ? p->What64 : nullptr;
     a.Cx = p->Cx;
     a.Vpart = p->Vpart;
+    a.vpart_f64 = p->cov_f64() ? 1 : 0;
     a.wscale = (!init_only && p->wscale_pending) ? p->wscale : nullptr;
     a.nsplit = p->cov.nsplit;
     a.T = p->T;
@@ -198,10 +209,10 @@ int stage_update(oiva_plan* p, bool init_only) {
     a.M = p->M;
     a.K = p->K;
     a.init_only = init_only ? 1 : 0;
-    a.use_double = p->use_double & 1;
-    a.layout = (p->use_double >> 1) & 1;
-    a.dbg = p->use_double >> 8;
+    a.use_double = p->upd_f64() ? 1 : 0;
+    a.layout = (p->prec & OIVA_PREC_UPDATE_ROWS) ? 1 : 0;
     HIP_TRY(launch_update(p->stream, a));
+    p->what64_valid = a.What64 != nullptr;      // the float32 variants leave the complex128 copy behind
     if (!init_only) p->wscale_pending = false;
     return OIVA_OK;
 }
@@ -243,6 +254,31 @@ int build_graphs(oiva_plan* p) {
     p->wscale_pending = pending;   // capturing toggled the host-side flags without running anything
     p->raw_weights = raw;
     return rc;
+}
+
+// W_hat lives twice on the device: complex64 for the streaming kernels, complex128 for the float64 update
+int upload_what(oiva_plan* p, const std::vector<double2>& wh) {
+    std::vector<float2> w32(wh.size());
+    for (size_t i = 0; i < wh.size(); ++i) w32[i] = make_float2((float)wh[i].x, (float)wh[i].y);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(p->What, w32.data(), w32.size() * sizeof(float2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->What64, wh.data(), wh.size() * sizeof(double2), hipMemcpyHostToDevice));
+    p->what64_valid = true;
+    return OIVA_OK;
+}
+
+// the current W_hat in float64: the complex128 copy when the float64 update maintains it, else the complex64 one
+int download_what(oiva_plan* p, std::vector<double2>& wh) {
+    wh.resize((size_t)p->F * p->M * p->M);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->what64_valid) {
+        HIP_TRY(hipMemcpy(wh.data(), p->What64, wh.size() * sizeof(double2), hipMemcpyDeviceToHost));
+        return OIVA_OK;
+    }
+    std::vector<float2> w32(wh.size());
+    HIP_TRY(hipMemcpy(w32.data(), p->What, w32.size() * sizeof(float2), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < wh.size(); ++i) wh[i] = make_double2(w32[i].x, w32[i].y);
+    return OIVA_OK;
 }
 
 int check_ready(oiva_plan* p) {
@@ -326,14 +362,16 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
         if (e == hipSuccess) e = hipMalloc(ptr, bytes);
     };
     alloc((void**)&p->What, nFMM * sizeof(float2));
-    alloc((void**)&p->Cx, nFMM * sizeof(float));
+    alloc((void**)&p->What64, nFMM * sizeof(double2));
+    alloc((void**)&p->Cx, nFMM * sizeof(double));
     alloc((void**)&p->Ppart, (size_t)p->pw.nb * nTK * sizeof(float));
     p->ppart_alloc = p->pw.nb;
     alloc((void**)&p->Plocal, std::max(nTK, (size_t)T * 16) * sizeof(float));   // also the (T, 16) weights scratch
     alloc((void**)&p->R, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));   // zeroed tail rows: see cov_dma_kernel
     if (e == hipSuccess) e = hipMemset(p->R, 0, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));
     alloc((void**)&p->wscale, (size_t)K * sizeof(float));
-    alloc((void**)&p->scratch_c, (size_t)std::max(1, K) * nFMM * sizeof(float2));
+    alloc((void**)&p->scratch_c, (size_t)K * nFMM * sizeof(double2));
+    alloc((void**)&p->scratch_p, std::max((size_t)K * nFMM, nTK) * sizeof(double));
     for (auto& ev : p->ev) {
         if (e == hipSuccess) e = hipEventCreate(&ev);
     }
@@ -356,8 +394,8 @@ int oiva_plan_destroy(oiva_plan* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->graph_batch_exec) (void)hipGraphExecDestroy(p->graph_batch_exec);
-    void* bufs[] = {p->X_owned, p->What, p->Cx,     p->Vpart, p->Ppart, p->Plocal, p->R,
-                    p->wscale, p->Spart, p->Y,     p->scratch_c};
+    void* bufs[] = {p->X_owned, p->What, p->What64, p->Cx,        p->Vpart,    p->Ppart, p->Plocal,
+                    p->R,       p->wscale, p->Spart, p->Y,      p->scratch_c, p->scratch_p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& ev : p->ev)
@@ -408,38 +446,47 @@ int oiva_plan_covariance(oiva_plan* p) {
     CovGeom g = p->cov;
     g.kc = 1;
     // unit weights, one "source": partials land in Vpart laid out as [nsplit][F][1][M*M]
-    HIP_TRY(launch_cov(p->stream, p->X, nullptr, nullptr, nullptr, p->model, 0, p->Vpart, p->T, p->F, p->M, 1, g));
-    HIP_TRY(launch_sum_parts(p->stream, p->Vpart, g.nsplit, p->Cx, (long long)p->F * p->M * p->M, 1.f / (float)p->T));
+    HIP_TRY(launch_cov(p->stream, p->X, nullptr, nullptr, nullptr, p->model, 0, p->Vpart, p->cov_f64(), p->T, p->F, p->M, 1, g));
+    HIP_TRY(launch_sum_parts(p->stream, p->Vpart, p->cov_f64(), g.nsplit, p->Cx, (long long)p->F * p->M * p->M, 1. / (double)p->T));
     p->have_cx = true;
     return OIVA_OK;
 }
 
-int oiva_plan_get_cx(oiva_plan* p, void* Cx_host) {
+int oiva_plan_get_cx(oiva_plan* p, void* Cx_host, int f64) {
     NEED(p && Cx_host, OIVA_ERR_ARG, "null argument");
     NEED(p->have_cx, OIVA_ERR_STATE, "input covariance not computed");
     DeviceGuard guard(p->device);
-    HIP_TRY(launch_unpack_herm(p->stream, p->Cx, p->scratch_c, p->F, p->M, 1.f));
+    const size_t n = (size_t)p->F * p->M * p->M;
+    HIP_TRY(launch_unpack_herm(p->stream, p->Cx, p->scratch_c, f64 != 0, p->F, p->M));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy(Cx_host, p->scratch_c, (size_t)p->F * p->M * p->M * sizeof(float2), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(Cx_host, p->scratch_c, n * (f64 ? sizeof(double2) : sizeof(float2)), hipMemcpyDeviceToHost));
     return OIVA_OK;
 }
 
-int oiva_plan_set_w(oiva_plan* p, const void* W0_host) {
+int oiva_plan_set_w(oiva_plan* p, const void* W0_host, int f64) {
     NEED(p, OIVA_ERR_ARG, "null plan");
     NEED(p->have_cx, OIVA_ERR_STATE, "input covariance not computed (needed for the orthogonality constraint)");
     DeviceGuard guard(p->device);
     const int F = p->F, M = p->M, K = p->K;
-    std::vector<float2> wh((size_t)F * M * M, make_float2(0.f, 0.f));
-    const float2* w0 = (const float2*)W0_host;
+    std::vector<double2> wh((size_t)F * M * M, make_double2(0., 0.));
     for (int f = 0; f < F; ++f) {
-        float2* m = wh.data() + (size_t)f * M * M;
+        double2* m = wh.data() + (size_t)f * M * M;
         for (int r = 0; r < M; ++r)
-            for (int k = 0; k < K; ++k)
-                m[r * M + k] = w0 ? w0[((size_t)f * M + r) * K + k] : make_float2(r == k ? 1.f : 0.f, 0.f);
-        for (int r = K; r < M; ++r) m[r * M + r] = make_float2(-1.f, 0.f);  // overiva.py:122-123
+            for (int k = 0; k < K; ++k) {
+                const size_t i = ((size_t)f * M + r) * K + k;
+                if (!W0_host) {
+                    m[r * M + k] = make_double2(r == k ? 1. : 0., 0.);           // overiva.py:113-114
+                } else if (f64) {
+                    m[r * M + k] = static_cast<const double2*>(W0_host)[i];       // overiva.py:116-117
+                } else {
+                    const float2 v = static_cast<const float2*>(W0_host)[i];
+                    m[r * M + k] = make_double2(v.x, v.y);
+                }
+            }
+        for (int r = K; r < M; ++r) m[r * M + r] = make_double2(-1., 0.);  // overiva.py:122-123
     }
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy(p->What, wh.data(), wh.size() * sizeof(float2), hipMemcpyHostToDevice));
+    int rc = upload_what(p, wh);
+    if (rc) return rc;
     p->wscale_pending = false;
     p->have_w = true;
     if (K < M) return stage_update(p, true);  // J from the orthogonality constraint, overiva.py:120-121
@@ -524,22 +571,25 @@ int oiva_plan_demix(oiva_plan* p, void* Y_host, long long row_pitch_bytes, int p
     return OIVA_OK;
 }
 
-int oiva_plan_get_w(oiva_plan* p, void* W_host) {
+int oiva_plan_get_w(oiva_plan* p, void* W_host, int f64) {
     NEED(p && W_host, OIVA_ERR_ARG, "null argument");
     NEED(p->have_w, OIVA_ERR_STATE, "demixing matrix not set");
     DeviceGuard guard(p->device);
     const int F = p->F, M = p->M, K = p->K;
-    std::vector<float2> wh((size_t)F * M * M);
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy(wh.data(), p->What, wh.size() * sizeof(float2), hipMemcpyDeviceToHost));
-    float2* w = (float2*)W_host;
+    std::vector<double2> wh;
+    int rc = download_what(p, wh);
+    if (rc) return rc;
     bool finite = true;
     for (int f = 0; f < F; ++f)
         for (int r = 0; r < M; ++r)
             for (int k = 0; k < K; ++k) {
-                const float2 v = wh[((size_t)f * M + r) * M + k];
+                const double2 v = wh[((size_t)f * M + r) * M + k];
                 finite = finite && std::isfinite(v.x) && std::isfinite(v.y);
-                w[((size_t)f * M + r) * K + k] = v;
+                const size_t i = ((size_t)f * M + r) * K + k;
+                if (f64)
+                    static_cast<double2*>(W_host)[i] = v;
+                else
+                    static_cast<float2*>(W_host)[i] = make_float2((float)v.x, (float)v.y);
             }
     if (!finite) return fail(OIVA_ERR_NUMERIC, "demixing matrix holds non-finite values (singular W_hat^H V)");
     return OIVA_OK;
@@ -646,13 +696,24 @@ int oiva_plan_use_graph(oiva_plan* p, int enable) {
     return OIVA_OK;
 }
 
-int oiva_plan_set_precision(oiva_plan* p, int fp64_update) {
+int oiva_plan_set_precision(oiva_plan* p, int flags) {
     NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED((flags & ~(OIVA_PREC_UPDATE_F64 | OIVA_PREC_UPDATE_ROWS | OIVA_PREC_COV_F64)) == 0, OIVA_ERR_ARG, "unknown precision flag");
     DeviceGuard guard(p->device);
     HIP_TRY(hipStreamSynchronize(p->stream));
     int rc = drop_graph(p);
     if (rc) return rc;
-    p->use_double = fp64_update;   // bit 0: fp64, bit 1: row-per-lane layout, bits 8+: ablation mask (tuning only)
+    if ((flags & OIVA_PREC_UPDATE_F64) && p->have_w && !p->what64_valid) {
+        // switching the update to float64 mid-run: seed the complex128 copy from the complex64 state
+        std::vector<double2> wh;
+        if ((rc = download_what(p, wh)) || (rc = upload_what(p, wh))) return rc;
+    }
+    const bool cov_changed = ((flags ^ p->prec) & OIVA_PREC_COV_F64) != 0;
+    p->prec = flags;
+    if (cov_changed) {
+        choose_cov_geom(p, 0);            // sources per pass and residency depend on the accumulator type
+        if ((rc = ensure_vpart(p))) return rc;
+    }
     return OIVA_OK;
 }
 
@@ -700,26 +761,23 @@ int oiva_test_run_weighted_cov(oiva_plan* p) {
     return stage_cov(p);
 }
 
-int oiva_test_get_v(oiva_plan* p, void* V_host) {
+int oiva_test_get_v(oiva_plan* p, void* V_host, int f64) {
     NEED(p && V_host, OIVA_ERR_ARG, "null argument");
     DeviceGuard guard(p->device);
     const int F = p->F, M = p->M, K = p->K;
     const long long nfk = (long long)F * K * M * M;
-    float* packed = nullptr;
-    HIP_TRY(hipMalloc(&packed, nfk * sizeof(float)));
-    hipError_t e = launch_sum_parts(p->stream, p->Vpart, p->cov.nsplit, packed, nfk, 1.f / (float)p->T);
-    if (e == hipSuccess) e = launch_unpack_herm(p->stream, packed, p->scratch_c, (long long)F * K, M, 1.f);
-    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-    std::vector<float2> fk((size_t)nfk);
-    if (e == hipSuccess) e = hipMemcpy(fk.data(), p->scratch_c, fk.size() * sizeof(float2), hipMemcpyDeviceToHost);
-    (void)hipFree(packed);
-    HIP_TRY(e);
+    HIP_TRY(launch_sum_parts(p->stream, p->Vpart, p->cov_f64(), p->cov.nsplit, p->scratch_p, nfk, 1. / (double)p->T));
+    HIP_TRY(launch_unpack_herm(p->stream, p->scratch_p, p->scratch_c, f64 != 0, (long long)F * K, M));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    const size_t esz = f64 ? sizeof(double2) : sizeof(float2);
+    std::vector<char> fk((size_t)nfk * esz);
+    HIP_TRY(hipMemcpy(fk.data(), p->scratch_c, fk.size(), hipMemcpyDeviceToHost));
     // device order is [F][K][M][M]; the oracle's is (K, F, M, M)
-    float2* out = (float2*)V_host;
-    const size_t mm = (size_t)M * M;
+    char* out = (char*)V_host;
+    const size_t mm = (size_t)M * M * esz;
     for (int f = 0; f < F; ++f)
         for (int k = 0; k < K; ++k)
-            std::memcpy(out + ((size_t)k * F + f) * mm, fk.data() + ((size_t)f * K + k) * mm, mm * sizeof(float2));
+            std::memcpy(out + ((size_t)k * F + f) * mm, fk.data() + ((size_t)f * K + k) * mm, mm);
     return OIVA_OK;
 }
 
@@ -730,19 +788,33 @@ int oiva_test_run_update(oiva_plan* p) {
     return stage_update(p, false);
 }
 
-int oiva_test_get_what(oiva_plan* p, void* What_host) {
+int oiva_test_get_what(oiva_plan* p, void* What_host, int f64) {
     NEED(p && What_host, OIVA_ERR_ARG, "null argument");
     DeviceGuard guard(p->device);
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy(What_host, p->What, (size_t)p->F * p->M * p->M * sizeof(float2), hipMemcpyDeviceToHost));
+    std::vector<double2> wh;
+    int rc = download_what(p, wh);
+    if (rc) return rc;
+    if (f64) {
+        std::memcpy(What_host, wh.data(), wh.size() * sizeof(double2));
+    } else {
+        float2* o = static_cast<float2*>(What_host);
+        for (size_t i = 0; i < wh.size(); ++i) o[i] = make_float2((float)wh[i].x, (float)wh[i].y);
+    }
     return OIVA_OK;
 }
 
-int oiva_test_set_what(oiva_plan* p, const void* What_host) {
+int oiva_test_set_what(oiva_plan* p, const void* What_host, int f64) {
     NEED(p && What_host, OIVA_ERR_ARG, "null argument");
     DeviceGuard guard(p->device);
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy(p->What, What_host, (size_t)p->F * p->M * p->M * sizeof(float2), hipMemcpyHostToDevice));
+    std::vector<double2> wh((size_t)p->F * p->M * p->M);
+    if (f64) {
+        std::memcpy(wh.data(), What_host, wh.size() * sizeof(double2));
+    } else {
+        const float2* in = static_cast<const float2*>(What_host);
+        for (size_t i = 0; i < wh.size(); ++i) wh[i] = make_double2(in[i].x, in[i].y);
+    }
+    int rc = upload_what(p, wh);
+    if (rc) return rc;
     p->have_w = true;
     p->wscale_pending = false;
     return OIVA_OK;
@@ -779,9 +851,12 @@ int oiva_test_run_power(oiva_plan* p, float* p_host) {
     DeviceGuard guard(p->device);
     int rc = stage_power(p);
     if (rc) return rc;
-    HIP_TRY(launch_sum_parts(p->stream, p->Ppart, p->pw.nb, p->Plocal, (long long)p->T * p->K, 1.f));
+    const size_t n = (size_t)p->T * p->K;
+    HIP_TRY(launch_sum_parts(p->stream, p->Ppart, false, p->pw.nb, p->scratch_p, (long long)n, 1.));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy(p_host, p->Plocal, (size_t)p->T * p->K * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<double> sum(n);
+    HIP_TRY(hipMemcpy(sum.data(), p->scratch_p, n * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) p_host[i] = (float)sum[i];
     return OIVA_OK;
 }
 

@@ -1,9 +1,16 @@
 """Drop-in ``overiva()`` -- same name, argument order, defaults and return values as reference
 ``overiva.py:28-38``; the body runs on one MI355X (or bin-sharded over several, see ``sharded.py``).
 
+Arithmetic (``set_precision``): device data (X, Y) is complex64 whatever the input dtype.  In ``"precise"``
+mode the weighted covariance is accumulated in float64 on the fp64 matrix cores and the per-bin algebra runs in
+float64 with W_hat carried in complex128 -- the reference's complex128 arithmetic (``overiva.py:89,126-131``)
+applied to complex64-rounded data; in ``"fast"`` mode everything is float32.  ``"auto"`` (default) picks
+``"precise"`` for complex128 input and ``"fast"`` for complex64 input.
+
 Documented deviations from the reference:
-* arithmetic is float32/complex64 on the device whatever the input dtype; the result is cast back
-  to the input's complex dtype (the reference computes in the input dtype, ``overiva.py:89,126,131``);
+* X is held as complex64 on the device even for complex128 input (a 6e-8 relative input perturbation); the
+  result is cast back to the input's complex dtype;
+* at most 16 channels (``OIVA_MAX_CHANNELS``; the reference has no limit);
 * an unknown ``model`` raises ``ValueError`` (the reference silently returns NaN, ``overiva.py:152-167``);
 * the returned ``W`` is a fresh contiguous ``(n_freq, n_chan, n_src)`` array, not a view of ``W_hat``
   (``overiva.py:90,201-202``).
@@ -16,6 +23,26 @@ from . import sharded
 from .plan import Plan
 
 _device = None
+_precision = "auto"
+
+
+def set_precision(mode):
+    """Arithmetic of subsequent ``overiva()`` / ``auxiva_pca()`` calls: ``"auto"`` (default: ``"precise"`` for
+    complex128 input, ``"fast"`` for complex64), ``"fast"`` or ``"precise"`` (see the module docstring)."""
+    global _precision
+    if mode not in ("auto", "fast", "precise"):
+        raise ValueError("precision must be 'auto', 'fast' or 'precise'")
+    _precision = mode
+
+
+def get_precision():
+    return _precision
+
+
+def resolve_precision(dtype):
+    if _precision != "auto":
+        return _precision
+    return "precise" if np.dtype(dtype) == np.complex128 else "fast"
 
 
 def set_device(index):
@@ -43,7 +70,7 @@ def eig_init(Cx, n_src):
 
     Stays on the host: eigenvector phases are LAPACK's choice and the reference keeps them.
     """
-    vals, vecs = np.linalg.eig(Cx.astype(np.complex128))
+    vals, vecs = np.linalg.eig(np.asarray(Cx, dtype=np.complex128))
     F, M, _ = Cx.shape
     W0 = np.empty((F, M, n_src), dtype=np.complex128)
     for f in range(F):
@@ -105,11 +132,12 @@ def overiva(
     if n_iter < 0:
         raise ValueError("n_iter must be >= 0")
 
+    precision = resolve_precision(dtype)
     group = sharded.active_group()
     if group is not None:
-        solver = sharded.BinShardedSolver(n_frames, n_freq, n_chan, n_src, model, group=group[0])
+        solver = sharded.BinShardedSolver(n_frames, n_freq, n_chan, n_src, model, group=group[0], precision=precision)
     else:
-        solver = _SingleDevice(n_frames, n_freq, n_chan, n_src, model)
+        solver = _SingleDevice(n_frames, n_freq, n_chan, n_src, model, precision)
     try:
         solver.set_x(X)
         solver.covariance()
@@ -146,8 +174,10 @@ class _SingleDevice:
     # 2048x4000x8 4.1k eager vs 4.5k replayed)
     GRAPH_MIN_ELEMENTS = 1 << 23
 
-    def __init__(self, T, F, M, K, model):
+    def __init__(self, T, F, M, K, model, precision="fast"):
         self.plan = Plan(T, F, M, K, model, device=get_device())
+        self.plan.set_precision(precision)
+        self.wdtype = np.complex128 if precision == "precise" else np.complex64
         if T * F * M >= self.GRAPH_MIN_ELEMENTS:
             self.plan.use_graph(True)
 
@@ -170,7 +200,7 @@ class _SingleDevice:
         return self.plan.demix(proj_back)
 
     def get_w(self):
-        return self.plan.get_w()
+        return self.plan.get_w(self.wdtype)
 
     def close(self):
         self.plan.close()

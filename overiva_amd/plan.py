@@ -6,6 +6,14 @@ import numpy as np
 from . import _lib
 
 
+def _is_f64(a):
+    if a.dtype == np.complex128:
+        return 1
+    if a.dtype == np.complex64:
+        return 0
+    raise TypeError(f"complex64 or complex128 expected, got {a.dtype}")
+
+
 class Plan:
     """Owns the device state of one AuxIVA/OverIVA problem (or one bin shard of it).
 
@@ -69,17 +77,20 @@ class Plan:
     def covariance(self):
         _lib.check(self.lib.oiva_plan_covariance(self.h))
 
-    def get_cx(self):
-        out = np.empty((self.F, self.M, self.M), np.complex64)
-        _lib.check(self.lib.oiva_plan_get_cx(self.h, _lib.ptr(out)))
+    def get_cx(self, dtype=np.complex128):
+        """input covariance (F, M, M); the device holds it in float64"""
+        out = np.empty((self.F, self.M, self.M), dtype)
+        _lib.check(self.lib.oiva_plan_get_cx(self.h, _lib.ptr(out), _is_f64(out)))
         return out
 
     def set_w(self, W0=None):
         if W0 is None:
-            _lib.check(self.lib.oiva_plan_set_w(self.h, None))
+            _lib.check(self.lib.oiva_plan_set_w(self.h, None, 0))
             return
-        W0 = np.ascontiguousarray(np.broadcast_to(np.asarray(W0), (self.F, self.M, self.K)), dtype=np.complex64)
-        _lib.check(self.lib.oiva_plan_set_w(self.h, _lib.ptr(W0)))
+        W0 = np.asarray(W0)
+        dt = np.complex64 if W0.dtype == np.complex64 else np.complex128
+        W0 = np.ascontiguousarray(np.broadcast_to(W0, (self.F, self.M, self.K)), dtype=dt)
+        _lib.check(self.lib.oiva_plan_set_w(self.h, _lib.ptr(W0), _is_f64(W0)))
 
     # -- iteration ----------------------------------------------------------------------------
     def iterate(self, n=1):
@@ -123,9 +134,9 @@ class Plan:
         _lib.check(self.lib.oiva_plan_demix(self.h, C.c_void_p(base), pitch, 1 if proj_back else 0))
         return out
 
-    def get_w(self):
-        out = np.empty((self.F, self.M, self.K), np.complex64)
-        _lib.check(self.lib.oiva_plan_get_w(self.h, _lib.ptr(out)))
+    def get_w(self, dtype=np.complex64):
+        out = np.empty((self.F, self.M, self.K), dtype)
+        _lib.check(self.lib.oiva_plan_get_w(self.h, _lib.ptr(out), _is_f64(out)))
         return out
 
     def sync(self):
@@ -146,8 +157,13 @@ class Plan:
     def use_graph(self, enable=True):
         _lib.check(self.lib.oiva_plan_use_graph(self.h, 1 if enable else 0))
 
-    def set_precision(self, fp64_update, row_layout=False):
-        _lib.check(self.lib.oiva_plan_set_precision(self.h, (1 if fp64_update else 0) | (2 if row_layout else 0)))
+    def set_precision(self, mode="fast", row_layout=False):
+        """``"fast"`` (float32 everywhere), ``"precise"`` (float64 covariance accumulation and per-bin algebra:
+        the reference's complex128 arithmetic on complex64 data), or an int of ``_lib.PREC_*`` bits."""
+        flags = {"fast": _lib.PREC_FAST, "precise": _lib.PREC_PRECISE}[mode] if isinstance(mode, str) else int(mode)
+        if row_layout:
+            flags |= _lib.PREC_UPDATE_ROWS
+        _lib.check(self.lib.oiva_plan_set_precision(self.h, flags))
 
     # -- test-only stage access -----------------------------------------------------------------
     def t_set_rinv(self, rinv):
@@ -164,31 +180,29 @@ class Plan:
     def t_run_weighted_cov(self):
         _lib.check(self.lib.oiva_test_run_weighted_cov(self.h))
 
-    def t_get_v(self):
-        v = np.empty((self.K, self.F, self.M, self.M), np.complex64)
-        _lib.check(self.lib.oiva_test_get_v(self.h, _lib.ptr(v)))
+    def t_get_v(self, dtype=np.complex64):
+        v = np.empty((self.K, self.F, self.M, self.M), dtype)
+        _lib.check(self.lib.oiva_test_get_v(self.h, _lib.ptr(v), _is_f64(v)))
         return v
 
     def t_run_update(self):
         _lib.check(self.lib.oiva_test_run_update(self.h))
 
-    def t_get_what(self):
-        w = np.empty((self.F, self.M, self.M), np.complex64)
-        _lib.check(self.lib.oiva_test_get_what(self.h, _lib.ptr(w)))
+    def t_get_what(self, dtype=np.complex64):
+        w = np.empty((self.F, self.M, self.M), dtype)
+        _lib.check(self.lib.oiva_test_get_what(self.h, _lib.ptr(w), _is_f64(w)))
         return w
 
     def t_set_what(self, What):
-        What = np.ascontiguousarray(What, dtype=np.complex64)
+        What = np.asarray(What)
+        What = np.ascontiguousarray(What, dtype=np.complex64 if What.dtype == np.complex64 else np.complex128)
         assert What.shape == (self.F, self.M, self.M)
-        _lib.check(self.lib.oiva_test_set_what(self.h, _lib.ptr(What)))
+        _lib.check(self.lib.oiva_test_set_what(self.h, _lib.ptr(What), _is_f64(What)))
 
     def t_time_stage(self, stage, reps=20):
         ms = C.c_float()
         _lib.check(self.lib.oiva_test_time_stage(self.h, _lib.STAGE_NAMES.index(stage), int(reps), C.byref(ms)))
         return ms.value
-
-    def t_set_flags(self, flags):
-        _lib.check(self.lib.oiva_plan_set_precision(self.h, int(flags)))
 
     def t_run_power(self):
         p = np.empty((self.T, self.K), np.float32)

@@ -46,7 +46,7 @@ def shard_bounds(n_freq, world):
 class HipEngine:
     """the product engine: one ``Plan`` on this rank's GPU, launched on torch's current stream"""
 
-    def __init__(self, T, F_local, M, K, model, F_total, device):
+    def __init__(self, T, F_local, M, K, model, F_total, device, precision="fast"):
         import torch
 
         from .plan import Plan
@@ -60,6 +60,8 @@ class HipEngine:
         cur = torch.cuda.current_stream(self.device)
         self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(device=self.device)
         self.plan = Plan(T, F_local, M, K, model, device=device, F_total=F_total, stream=self.stream.cuda_stream)
+        self.plan.set_precision(precision)
+        self.wdtype = np.complex128 if precision == "precise" else np.complex64
         self.T, self.K = T, K
 
     def stream_ctx(self):
@@ -115,7 +117,7 @@ class HipEngine:
         return self.plan.demix(proj_back)
 
     def get_w(self):
-        return self.plan.get_w()
+        return self.plan.get_w(self.wdtype)
 
     def to_comm(self, a):
         return self.torch.from_numpy(a).to(self.device)
@@ -130,7 +132,7 @@ class HipEngine:
 class BinShardedSolver:
     """Same stage interface as the single-GPU solver in ``overiva.py``, over a process group."""
 
-    def __init__(self, T, F, M, K, model, group=None, engine_factory=None, device=None):
+    def __init__(self, T, F, M, K, model, group=None, engine_factory=None, device=None, precision="fast"):
         import torch.distributed as dist
 
         self.dist = dist
@@ -146,7 +148,7 @@ class BinShardedSolver:
             from .overiva import get_device
 
             dev = get_device() if device is None else device
-            self.engine = HipEngine(T, self.f1 - self.f0, M, K, model, F, dev)
+            self.engine = HipEngine(T, self.f1 - self.f0, M, K, model, F, dev, precision)
         else:
             self.engine = engine_factory(T, self.f1 - self.f0, M, K, model, F)
         # every rank sends the same number of (T, K) parts: the largest batch count of any shard
@@ -180,25 +182,37 @@ class BinShardedSolver:
         return self._gather_bins(self.engine.demix(proj_back), axis=1)
 
     def get_w(self):
-        return self._gather_bins(self.engine.get_w(), axis=0)
+        # gather first, judge afterwards: a singular bin on ONE rank must raise on EVERY rank, not leave the
+        # others waiting in the collective
+        try:
+            local, err = self.engine.get_w(), None
+        except np.linalg.LinAlgError as e:
+            local, err = np.full((self.f1 - self.f0, self.M, self.K), np.nan, np.complex64), e
+        W = self._gather_bins(local, axis=0)
+        if err is not None or not np.all(np.isfinite(W)):
+            raise np.linalg.LinAlgError(str(err) if err is not None else
+                                        "demixing matrix holds non-finite values on another rank (singular W_hat^H V)")
+        return W
 
     def close(self):
         self.engine.close()
 
     # ---- helpers --------------------------------------------------------------------------------
     def _gather_bins(self, local, axis):
-        """concatenate per-rank complex64 arrays along the bin axis on every rank"""
+        """concatenate per-rank complex arrays along the bin axis on every rank"""
         import torch
 
         local = np.ascontiguousarray(np.moveaxis(local, axis, 0))          # (F_local, ...)
+        cdt = local.dtype
+        rdt = np.float64 if cdt == np.complex128 else np.float32
         rest = local.shape[1:]
         fmax = max(self.bounds[r + 1] - self.bounds[r] for r in range(self.world))
-        pad = np.zeros((fmax,) + rest, dtype=np.complex64)
+        pad = np.zeros((fmax,) + rest, dtype=cdt)
         pad[: local.shape[0]] = local
-        send = self.engine.to_comm(pad.view(np.float32))
+        send = self.engine.to_comm(pad.view(rdt))
         recv = torch.empty((self.world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype,
                            device=send.device)
         self.dist.all_gather_into_tensor(recv, send, group=self.group)
-        full = recv.cpu().numpy().view(np.complex64).reshape((self.world, fmax) + rest)
+        full = recv.cpu().numpy().view(cdt).reshape((self.world, fmax) + rest)
         parts = [full[r, : self.bounds[r + 1] - self.bounds[r]] for r in range(self.world)]
         return np.moveaxis(np.concatenate(parts, axis=0), 0, axis)
