@@ -63,6 +63,7 @@ struct oiva_plan {
     double* scratch_p = nullptr;   // K*F*M*M packed float64, for getters
 
     CovGeom cov{};
+    CovGeom stg{};              // geometry of the projection-back statistics pass (16-bin groups, independent of cov)
     PowGeom pw{};
     int n_cu = 256;
     int vpart_splits_alloc = 0;
@@ -132,6 +133,17 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     p->cov = g;
 }
 
+void choose_stats_geom(oiva_plan* p) {
+    CovGeom g;
+    g.nbg = ceil_div(p->F, kBinsPerWave);
+    g.kc = 2;
+    const int nz = ceil_div(p->K, g.kc);
+    const int nsplit = std::min(16, pick_splits(p->n_cu * 4, g.nbg * nz, p->T, 128));
+    g.tc = round_up(ceil_div(p->T, nsplit), 16);
+    g.nsplit = ceil_div(p->T, g.tc);
+    p->stg = g;
+}
+
 void choose_pow_geom(oiva_plan* p, int nsplit_req) {
     PowGeom g;
     g.nb = ceil_div(p->F, kBinsPerWave * kWaves);
@@ -170,10 +182,7 @@ int ensure_vpart(oiva_plan* p) {
     if (p->cov.nsplit > p->vpart_splits_alloc) {
         if (p->Vpart) HIP_TRY(hipFree(p->Vpart));
         p->Vpart = nullptr;
-        if (p->Spart) HIP_TRY(hipFree(p->Spart));
-        p->Spart = nullptr;
         HIP_TRY(hipMalloc(&p->Vpart, vpart_floats(p, p->cov.nsplit) * sizeof(double)));   // either element type
-        HIP_TRY(hipMalloc(&p->Spart, (size_t)p->cov.nsplit * p->F * p->K * 3 * sizeof(float)));
         p->vpart_splits_alloc = p->cov.nsplit;
     }
     return OIVA_OK;
@@ -355,6 +364,7 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     }
     choose_cov_geom(p, 0);
     choose_pow_geom(p, 0);
+    choose_stats_geom(p);
     const size_t nTK = (size_t)T * K;
     const size_t nFMM = (size_t)F * M * M;
     hipError_t e = hipSuccess;
@@ -370,6 +380,7 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     alloc((void**)&p->R, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));   // zeroed tail rows: see cov_dma_kernel
     if (e == hipSuccess) e = hipMemset(p->R, 0, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));
     alloc((void**)&p->wscale, (size_t)K * sizeof(float));
+    alloc((void**)&p->Spart, (size_t)p->stg.nsplit * F * K * 3 * sizeof(float));
     alloc((void**)&p->scratch_c, (size_t)K * nFMM * sizeof(double2));
     alloc((void**)&p->scratch_p, std::max((size_t)K * nFMM, nTK) * sizeof(double));
     for (auto& ev : p->ev) {
@@ -562,10 +573,10 @@ int oiva_plan_demix(oiva_plan* p, void* Y_host, long long row_pitch_bytes, int p
     if (!p->Y) HIP_TRY(hipMalloc(&p->Y, row * p->T));
     const float* sp = nullptr;
     if (proj_back) {
-        HIP_TRY(launch_demix_stats(p->stream, p->X, p->What, p->Spart, p->T, p->F, p->M, p->K, p->cov));
+        HIP_TRY(launch_demix_stats(p->stream, p->X, p->What, p->Spart, p->T, p->F, p->M, p->K, p->stg));
         sp = p->Spart;
     }
-    HIP_TRY(launch_demix_write(p->stream, p->X, p->What, sp, p->cov.nsplit, p->Y, p->T, p->F, p->M, p->K));
+    HIP_TRY(launch_demix_write(p->stream, p->X, p->What, sp, p->stg.nsplit, p->Y, p->T, p->F, p->M, p->K));
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemcpy2D(Y_host, pitch, p->Y, row, row, p->T, hipMemcpyDeviceToHost));
     return OIVA_OK;

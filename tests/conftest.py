@@ -33,6 +33,13 @@ def golden(request):
     return g
 
 
+def need(g, *keys):
+    """skip when a fixture does not hold an entry (the F >= 64 fixtures store W only, for n_iter 1, 5, 20)"""
+    for k in keys:
+        if k not in g:
+            pytest.skip(f"fixture {g['_id']} has no {k}")
+
+
 AMP_LIMIT = 1e3
 
 

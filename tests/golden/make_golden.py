@@ -79,6 +79,16 @@ CASES = [
 ]
 N_ITERS = (0, 1, 2, 5, 20)
 
+# Larger, better conditioned shapes (F >= 64 bins, T >= 200 frames): with this many bins the gauss model's
+# activation r = sum_f |y|^2 / F no longer gets arbitrarily close to 0, so 20 iterations of it can be pinned
+# instead of skipped (amp_* stays small).  Only W is stored (Y = demix(X, W) follows from it).
+BIG_CASES = [
+    ("h", 200, 64, 4, 2),
+    ("i", 200, 64, 8, 2),
+    ("j", 208, 64, 6, 3),
+]
+BIG_ITERS = (1, 5, 20)
+
 
 def make_input(family, T, F, M, K, seed):
     if family == "iid":
@@ -116,6 +126,9 @@ def trace_intermediates(ref_overiva, X, K, n_iter, model):
 
 def main():
     ref_overiva, ref_pca = import_reference()
+    if "--big-only" in sys.argv:
+        make_big(ref_overiva, ref_pca)
+        return
     total = 0
     for name, T, F, M, K in CASES:
         for family in ("iid", "mix"):
@@ -197,7 +210,47 @@ def main():
             sz = os.path.getsize(path)
             total += sz
             print(f"{path}: {len(out)} arrays, {sz / 1024:.0f} KiB")
+    total += make_big(ref_overiva, ref_pca)
     print(f"total {total / 1e6:.2f} MB")
+
+
+def make_big(ref_overiva, ref_pca):
+    total = 0
+    for name, T, F, M, K in BIG_CASES:
+        for family in ("iid", "mix"):
+            seed = 2000 + ord(name) + (0 if family == "iid" else 500)
+            X64 = make_input(family, T, F, M, K, seed)
+            out = {"X": X64, "T": T, "F": F, "M": M, "K": K}
+            nonfinite = []
+            pert = 1.0 + 1e-12 * np.random.default_rng(seed + 2).standard_normal(X64.shape)
+            for dt_name, X in (("c64", X64), ("c128", X64.astype(np.complex128))):
+                for model in ("laplace", "gauss"):
+                    for n_iter in BIG_ITERS:
+                        Y, W = ref_overiva.overiva(X.copy(), n_src=K, n_iter=n_iter, proj_back=False, model=model,
+                                                   return_filters=True)
+                        key = f"{dt_name}_{model}_{n_iter}"
+                        if not (np.all(np.isfinite(W)) and np.all(np.isfinite(Y))):
+                            nonfinite.append(key)
+                            continue
+                        out[f"W_{key}"] = np.ascontiguousarray(W)
+                        if dt_name == "c128":
+                            _, Wp = ref_overiva.overiva(X * pert, n_src=K, n_iter=n_iter, proj_back=False, model=model,
+                                                        return_filters=True)
+                            out[f"amp_{model}_{n_iter}"] = np.float64(np.linalg.norm(Wp - W) / np.linalg.norm(W) / 1e-12)
+            X128 = X64.astype(np.complex128)
+            # proj_back epilogue: per-(bin, source) scale z, stored through W-sized quantities only: Y[0] rows
+            Ypb = ref_overiva.overiva(X128.copy(), n_src=K, n_iter=12, proj_back=True, model="laplace")
+            out["Ypb_frame0_c128_laplace_12"] = Ypb[0]                      # (F, K): pins z without storing (T, F, K)
+            Ypca = ref_pca.auxiva_pca(X128.copy(), n_src=K, n_iter=5, proj_back=True, model="laplace")
+            out["Ypca_frame0_c128_laplace_5"] = Ypca[0]
+            out["nonfinite"] = np.array(nonfinite, dtype="U32")
+            path = os.path.join(HERE, f"overiva_{name}_{family}.npz")
+            np.savez_compressed(path, **out)
+            sz = os.path.getsize(path)
+            total += sz
+            print(f"{path}: {len(out)} arrays, {sz / 1024:.0f} KiB; amps",
+                  {k: round(float(v), 1) for k, v in out.items() if k.startswith("amp_")})
+    return total
 
 
 if __name__ == "__main__":

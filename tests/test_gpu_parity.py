@@ -1,17 +1,30 @@
 """Parity of the HIP path (through the C ABI, ctypes) against the oracle and the committed golden
 vectors of the real reference.  Needs an MI355X: run with ``-m gpu``.
 
-Tolerances.  BASELINE.json's north_star asks for 1e-5 relative (fp32) on demixed Y and final W for
-identical STFT input.  The distance is ||a-b||_F / ||b||_F against the reference's complex128 result
-(the reference's own complex64 run sits 7e-7 .. 3e-5 from it).  Where the
-reference itself amplifies rounding (fixture key ``amp_*`` = measured amplification of a relative
-input perturbation, see tests/golden/make_golden.py) the bound is scaled by that amplification; where
-it is chaotic (amp > 1e3) nothing is compared (conftest.chaotic).
+Tolerances.  BASELINE.json's north_star asks for 1e-5 relative (fp32) on demixed Y and final W for identical
+STFT input; the distance is ||a-b||_F / ||b||_F.
+
+* Default arithmetic (``precise``: float64 covariance accumulation and per-bin algebra on complex64 data):
+  - against the reference's complex128 result: ``1e-5``, scaled by ``amp / 10`` only where the reference itself
+    amplifies rounding by more than 10 (fixture key ``amp_*`` = measured amplification of a relative input
+    perturbation in the reference, tests/golden/make_golden.py); nothing is compared where it is chaotic
+    (amp > 1e3, conftest.chaotic);
+  - for complex64 input additionally against the reference's OWN complex64 result (``W_c64_*``):
+    ``max(1e-5, 1.5 * floor)`` with floor = distance between the reference's complex64 and complex128 results.
+* ``fast`` arithmetic (float32 everywhere, the mode bench.py times): 1e-5 on well-conditioned (i.i.d.) input;
+  on mixture-like input a documented envelope of FAST_FLOORS reference floors (the all-float32 covariance
+  chains are what limits it, tests/precision_study.py) -- an accuracy statement of that mode, not the parity claim.
+
+Every end-to-end comparison appends a row to $OIVA_PARITY_LOG (JSON lines) when that variable is set;
+profiles/r02_parity_errors.md is made from it.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
-from conftest import chaotic, golden_files, golden_ids
+from conftest import chaotic, golden_files, golden_ids, need
 from oracle import overiva_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -19,22 +32,41 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5          # the north_star bound
 TOL_KERNEL = 3e-6   # single-kernel bound (one fp32 pass, no iteration feedback)
 TOL_KERNEL_F64 = 1e-12   # float64 accumulation of exact float32 products
+FAST_FLOORS = 6.0   # envelope of the float32 mode on ill-conditioned input, in reference-complex64 floors
 
 
 def _amp(g, model, n_iter):
     return max(1.0, float(g.get(f"amp_{model}_{n_iter}", 1.0)))
 
 
+def _bound128(g, model, n_iter):
+    """bound against the reference's complex128 result: the north-star 1e-5, scaled only for amp > 10"""
+    return TOL * max(1.0, _amp(g, model, n_iter) / 10.0)
+
+
+def _log(**row):
+    path = os.environ.get("OIVA_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(row) + "\n")
+
+
 def _c64_floor(fn_ref64, ref128):
     """distance of the reference algorithm's OWN complex64 arithmetic (oracle, reference-faithful
-    mode) from its complex128 result on the same input: no float32 implementation can be expected
-    to sit closer to the complex128 result than a small multiple of this."""
+    mode) from its complex128 result on the same input"""
     try:
         with np.errstate(all="ignore"):
             e = orc.rel_err(fn_ref64(), ref128)
     except np.linalg.LinAlgError:
         return np.inf
     return e if np.isfinite(e) else np.inf
+
+
+@pytest.fixture
+def fast_mode(oa):
+    oa.set_precision("fast")
+    yield
+    oa.set_precision("precise")
 
 
 @pytest.fixture(scope="module")
@@ -127,7 +159,9 @@ def test_ip_update(oa, golden, model, fp64, rows):
             W_out = p.t_get_what()
         V = orc.weighted_cov_all(X, rinv)
         ref = orc.ip_update_bin(W_in, V, orc.input_covariance(X.astype(np.complex128)), K)
-        assert orc.rel_err(W_out, ref) < 2e-5, (e, orc.rel_err(W_out, ref))
+        err = orc.rel_err(W_out, ref)
+        _log(test="ip_update", fixture=golden["_id"], model=model, epoch=e, fp64=fp64, rows=rows, What_err=err)
+        assert err < 2e-5, (e, err)
 
 
 def test_j_initialisation(oa, golden):
@@ -162,10 +196,16 @@ def test_activation(oa, golden):
 # --------------------------------------------------------------------------------------------
 # end to end: overiva() against the reference's golden outputs
 # --------------------------------------------------------------------------------------------
+def _demix(X, W):
+    return np.einsum("tfm,fmk->tfk", X.astype(np.complex128), np.conj(W.astype(np.complex128)))
+
+
 @pytest.mark.parametrize("model", ["laplace", "gauss"])
 @pytest.mark.parametrize("n_iter", [0, 1, 2, 5, 20])
 @pytest.mark.parametrize("dt", ["c64", "c128"])
 def test_overiva_matches_reference(oa, golden, model, n_iter, dt):
+    """default arithmetic against the real reference's stored results"""
+    need(golden, f"W_c128_{model}_{n_iter}")
     if chaotic(golden, model, n_iter):
         pytest.skip("reference is ill-conditioned here (see conftest.chaotic)")
     X, K = golden["X"], int(golden["K"])
@@ -174,68 +214,104 @@ def test_overiva_matches_reference(oa, golden, model, n_iter, dt):
     assert Y.dtype == Xin.dtype and W.dtype == Xin.dtype
     assert Y.shape == (X.shape[0], X.shape[1], K) and W.shape == (X.shape[1], X.shape[2], K)
     assert W.flags["C_CONTIGUOUS"]
-    refW = golden[f"W_c128_{model}_{n_iter}"]
-    eW = orc.rel_err(W, refW)
-    # floor: the real reference's own complex64 run on this input (stored next to its complex128 run)
+    ref128 = golden[f"W_c128_{model}_{n_iter}"]
+    e128 = orc.rel_err(W, ref128)
+    b128 = _bound128(golden, model, n_iter)
+    eY = orc.rel_err(Y, _demix(X, ref128))
     k64 = f"W_c64_{model}_{n_iter}"
-    floor = orc.rel_err(golden[k64], refW) if k64 in golden else 0.0
-    # (a float32 implementation lands within a small multiple of that floor, not below it: on the 16-channel
-    # determined mixture with 64 frames the last-bit rounding of a reciprocal moves the result by 3x)
-    bound = max(TOL * _amp(golden, model, n_iter), 5 * floor)
-    print(f"\n[parity] {golden['_id']} {model} n_iter={n_iter} {dt}: W err {eW:.2e} (bound {bound:.1e})")
-    assert eW < bound
-    if n_iter == 20:
-        eY = orc.rel_err(Y, golden[f"Y_c128_{model}_20"])
-        print(f"[parity] {golden['_id']} {model} n_iter=20 {dt}: Y err {eY:.2e}")
-        assert eY < bound
+    floor = orc.rel_err(golden[k64], ref128) if k64 in golden else None
+    e64 = orc.rel_err(W, golden[k64]) if k64 in golden else None
+    _log(test="e2e", fixture=golden["_id"], model=model, n_iter=n_iter, input=dt, mode="precise", W_vs_c128=e128,
+         Y_vs_c128=eY, W_vs_ref_c64=e64, ref_c64_floor=floor, amp=_amp(golden, model, n_iter), bound_c128=b128)
+    print(f"\n[parity] {golden['_id']} {model} n_iter={n_iter} {dt}: W vs c128 {e128:.2e} (bound {b128:.1e}), Y {eY:.2e}"
+          + (f", W vs reference-c64 {e64:.2e} (floor {floor:.1e})" if floor is not None else ""))
+    assert e128 < b128 and eY < b128
+    if dt == "c64" and floor is not None:
+        assert e64 < max(TOL, 1.5 * floor)      # as close to the reference's complex64 run as its own noise allows
+
+
+@pytest.mark.parametrize("model", ["laplace", "gauss"])
+@pytest.mark.parametrize("n_iter", [1, 5, 20])
+def test_fast_mode_accuracy(oa, golden, fast_mode, model, n_iter):
+    """the float32 mode: 1e-5 where the reference is well conditioned, a documented envelope elsewhere"""
+    need(golden, f"W_c128_{model}_{n_iter}", f"W_c64_{model}_{n_iter}")
+    if chaotic(golden, model, n_iter):
+        pytest.skip("reference is ill-conditioned here (see conftest.chaotic)")
+    X, K = golden["X"], int(golden["K"])
+    _, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=False, model=model, return_filters=True)
+    ref128 = golden[f"W_c128_{model}_{n_iter}"]
+    floor = orc.rel_err(golden[f"W_c64_{model}_{n_iter}"], ref128)
+    e128 = orc.rel_err(W, ref128)
+    _log(test="e2e", fixture=golden["_id"], model=model, n_iter=n_iter, input="c64", mode="fast", W_vs_c128=e128,
+         Y_vs_c128=None, W_vs_ref_c64=orc.rel_err(W, golden[f"W_c64_{model}_{n_iter}"]), ref_c64_floor=floor,
+         amp=_amp(golden, model, n_iter), bound_c128=max(TOL, FAST_FLOORS * floor))
+    print(f"\n[parity] {golden['_id']} {model} n_iter={n_iter} fast: W vs c128 {e128:.2e} = {e128 / floor:.1f} reference floors")
+    assert e128 < max(TOL, FAST_FLOORS * floor)
 
 
 @pytest.mark.parametrize("model", ["laplace", "gauss"])
 def test_proj_back_and_callback(oa, golden, model):
+    need(golden, f"Ypb_c128_{model}_12")
     if chaotic(golden, model, 12):
         pytest.skip("reference is ill-conditioned here (see conftest.chaotic)")
     X, K = golden["X"], int(golden["K"])
-    floor = _c64_floor(lambda: orc.overiva_faithful(X, n_src=K, n_iter=12, proj_back=True, model=model),
-                       golden[f"Ypb_c128_{model}_12"])
-    if floor > 1e-3:
-        pytest.skip(f"the reference's own complex64 run is {floor:.1e} away from its complex128 run here")
     got = []
     Y = oa.overiva(X.astype(np.complex128), n_src=K, n_iter=12, proj_back=True, model=model,
                    callback=lambda y: got.append(np.array(y)))
-    bound = max(TOL * _amp(golden, model, 12), 10 * floor)
-    print(f"\n[parity] {golden['_id']} {model} proj_back 12 its: Y err "
-          f"{orc.rel_err(Y, golden[f'Ypb_c128_{model}_12']):.2e} (reference c64 floor {floor:.1e}, bound {bound:.1e})")
-    assert orc.rel_err(Y, golden[f"Ypb_c128_{model}_12"]) < bound
+    bound = _bound128(golden, model, 12)
+    e = orc.rel_err(Y, golden[f"Ypb_c128_{model}_12"])
+    _log(test="proj_back", fixture=golden["_id"], model=model, n_iter=12, input="c128", mode="precise", Y_vs_c128=e,
+         amp=_amp(golden, model, 12), bound_c128=bound)
+    print(f"\n[parity] {golden['_id']} {model} proj_back 12 its: Y err {e:.2e} (bound {bound:.1e})")
+    assert e < bound
     assert len(got) == 2 and got[0].shape == Y.shape and got[0].dtype == np.complex128
     if model == "laplace":
         assert orc.rel_err(got[0], golden["cb0_c128_laplace"]) < bound
         assert orc.rel_err(got[1], golden["cb10_c128_laplace"]) < bound
 
 
+def test_frame0_of_large_fixtures(oa, golden):
+    """the F >= 64 fixtures keep frame 0 of the projected-back outputs (pins z of every bin and source)"""
+    need(golden, "Ypb_frame0_c128_laplace_12")
+    X, K = golden["X"].astype(np.complex128), int(golden["K"])
+    Y = oa.overiva(X, n_src=K, n_iter=12, proj_back=True, model="laplace")
+    e = orc.rel_err(Y[0], golden["Ypb_frame0_c128_laplace_12"])
+    Yp = oa.auxiva_pca(X, n_src=K, n_iter=5, proj_back=True, model="laplace")
+    ep = orc.rel_err(Yp[0], golden["Ypca_frame0_c128_laplace_5"])
+    _log(test="frame0", fixture=golden["_id"], model="laplace", n_iter=12, input="c128", mode="precise", Y_vs_c128=e,
+         pca_Y_vs_c128=ep)
+    print(f"\n[parity] {golden['_id']} proj_back frame 0: overiva {e:.2e}, auxiva_pca {ep:.2e}")
+    assert e < _bound128(golden, "laplace", 20) and ep < 2 * _bound128(golden, "laplace", 20)
+
+
 def test_warm_start_default_nsrc_eig(oa, golden):
+    need(golden, "W0")
     X, K = golden["X"], int(golden["K"])
     X128 = X.astype(np.complex128)
     _, W = oa.overiva(X128, n_src=K, n_iter=3, proj_back=False, W0=golden["W0"], return_filters=True)
-    floor = _c64_floor(lambda: orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=False, W0=golden["W0"],
-                                                    return_filters=True)[1], golden["W_w0_c128_laplace_3"])
-    assert orc.rel_err(W, golden["W_w0_c128_laplace_3"]) < max(TOL, 5 * floor)
+    e0 = orc.rel_err(W, golden["W_w0_c128_laplace_3"])
     _, W = oa.overiva(X128, n_iter=2, proj_back=False, return_filters=True)
     assert W.shape == golden["W_det_c128_laplace_2"].shape
-    floor = _c64_floor(lambda: orc.overiva_faithful(X, n_iter=2, proj_back=False, return_filters=True)[1],
-                       golden["W_det_c128_laplace_2"])
-    print(f"\n[parity] {golden['_id']} determined 2 its: W err "
-          f"{orc.rel_err(W, golden['W_det_c128_laplace_2']):.2e} (reference c64 floor {floor:.1e})")
-    assert orc.rel_err(W, golden["W_det_c128_laplace_2"]) < max(TOL, 5 * floor)
-    Y = oa.overiva(X128, n_src=K, n_iter=3, proj_back=False, init_eig=True)
+    e1 = orc.rel_err(W, golden["W_det_c128_laplace_2"])
+    Y, W = oa.overiva(X128, n_src=K, n_iter=3, proj_back=False, init_eig=True, return_filters=True)
     # eigenvector phase is LAPACK's choice: compare magnitudes
-    assert orc.rel_err(np.abs(Y), np.abs(golden["Y_eig_c128_laplace_3"])) < 1e-4
+    e2 = orc.rel_err(np.abs(Y), np.abs(golden["Y_eig_c128_laplace_3"]))
+    _log(test="warm/det/eig", fixture=golden["_id"], model="laplace", n_iter=3, input="c128", mode="precise", W_w0=e0,
+         W_det=e1, absY_eig=e2)
+    print(f"\n[parity] {golden['_id']} W0 3 its {e0:.2e}, determined 2 its {e1:.2e}, init_eig |Y| {e2:.2e}")
+    b = _bound128(golden, "laplace", 5)
+    assert e0 < b and e1 < b and e2 < b
 
 
 def test_auxiva_pca(oa, golden):
+    need(golden, "Ypca_c128_laplace_5")
     X, K = golden["X"], int(golden["K"])
     Y = oa.auxiva_pca(X.astype(np.complex128), n_src=K, n_iter=5, proj_back=True, model="laplace")
     assert Y.shape == golden["Ypca_c128_laplace_5"].shape and Y.dtype == np.complex128
-    assert orc.rel_err(Y, golden["Ypca_c128_laplace_5"]) < 1e-4
+    e = orc.rel_err(Y, golden["Ypca_c128_laplace_5"])
+    _log(test="auxiva_pca", fixture=golden["_id"], model="laplace", n_iter=5, input="c128", mode="precise", Y_vs_c128=e)
+    print(f"\n[parity] {golden['_id']} auxiva_pca 5 its: Y err {e:.2e}")
+    assert e < 2 * _bound128(golden, "laplace", 5)      # (the PCA projection of X is a float32 pass of its own)
     with pytest.raises(KeyError):
         oa.auxiva_pca(X.astype(np.complex128), n_src=K, n_iter=1)
 
@@ -249,26 +325,35 @@ def test_odd_shapes_against_oracle(oa, shape):
     for model in ("laplace", "gauss"):
         Y, W = oa.overiva(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
         Yr, Wr = orc.overiva_staged(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
-        floor = _c64_floor(lambda: orc.overiva_faithful(X, n_src=K, n_iter=4, proj_back=True, model=model,
-                                                        return_filters=True)[1], Wr)
         eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
-        print(f"\n[parity] T{T} F{F} M{M} K{K} {model} 4 its: W err {eW:.2e} Y err {eY:.2e} (reference c64 floor {floor:.1e})")
-        assert eW < max(TOL, 5 * floor) and eY < max(TOL, 5 * floor)
+        _log(test="odd_shape", fixture=f"T{T}F{F}M{M}K{K}", model=model, n_iter=4, input="c64", mode="precise", W_vs_c128=eW,
+             Y_vs_c128=eY)
+        print(f"\n[parity] T{T} F{F} M{M} K{K} {model} 4 its: W err {eW:.2e} Y err {eY:.2e}")
+        assert eW < TOL and eY < TOL
 
 
 @pytest.mark.parametrize("shape", [(5, 1, 1, 1), (17, 3, 2, 1), (33, 70, 3, 3), (5000, 2, 4, 2), (16, 16, 8, 8),
-                                   (2, 5, 2, 2), (1000, 1, 6, 2)])
+                                   (2, 5, 2, 2), (1000, 1, 6, 2), (337, 3, 4, 3), (1000, 40, 8, 2), (1029, 5, 8, 1)])
 def test_ragged_and_extreme_shapes(oa, shape):
-    """frames not a multiple of the 16-frame step, fewer bins than a 16-bin wave, single bin / channel,
-    very long and very short frame axes"""
+    """frames not a multiple of the 16-frame step (incl. frame counts that leave whole waves of the last step
+    past the end of the tensor), fewer bins than a 16-bin wave, single bin / channel, very long and very short
+    frame axes; both arithmetic modes"""
     T, F, M, K = shape
     X = orc.synth_iid(T, F, M, seed=7 + sum(shape))
-    Y, W = oa.overiva(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
     Yr, Wr = orc.overiva_staged(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
     if not np.all(np.isfinite(Wr)):
         pytest.skip("degenerate for the algorithm itself (oracle non-finite)")
     floor = _c64_floor(lambda: orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)[1], Wr)
-    assert orc.rel_err(W, Wr) < max(TOL, 5 * floor) and orc.rel_err(Y, Yr) < max(TOL, 5 * floor)
+    for mode in ("precise", "fast"):
+        oa.set_precision(mode)
+        try:
+            Y, W = oa.overiva(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
+        finally:
+            oa.set_precision("precise")
+        eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
+        print(f"\n[parity] T{T} F{F} M{M} K{K} {mode}: W err {eW:.2e} Y err {eY:.2e} (reference c64 floor {floor:.1e})")
+        fl = 1.5 if mode == "precise" else FAST_FLOORS
+        assert eW < max(TOL, fl * floor) and eY < max(TOL, fl * floor)
 
 
 def test_config1_shape_against_oracle(oa):
@@ -278,12 +363,12 @@ def test_config1_shape_against_oracle(oa):
     got, ref_got = [], []
     Y = oa.overiva(X, n_src=2, n_iter=20, proj_back=True, callback=lambda y: got.append(y.copy()))
     Yr = orc.overiva_staged(X, n_src=2, n_iter=20, proj_back=True, callback=lambda y: ref_got.append(y.copy()))
-    floor = _c64_floor(lambda: orc.overiva_faithful(X.astype(np.complex64), n_src=2, n_iter=20, proj_back=True), Yr)
     e = orc.rel_err(Y, Yr)
-    print(f"\n[parity] cfg1 shape mixture 20 its proj_back: Y err {e:.2e} (reference c64 floor {floor:.1e})")
+    _log(test="cfg1", fixture="T160F2049M4K2 mixture", model="laplace", n_iter=20, input="c128", mode="precise", Y_vs_c128=e)
+    print(f"\n[parity] cfg1 shape mixture 20 its proj_back: Y err {e:.2e}")
     assert Y.dtype == np.complex128 and len(got) == len(ref_got) == 2
-    assert e < max(TOL, 5 * floor)
-    assert orc.rel_err(got[1], ref_got[1]) < max(TOL, 5 * floor)
+    assert e < TOL
+    assert orc.rel_err(got[1], ref_got[1]) < TOL
 
 
 def test_errors(oa):
@@ -325,39 +410,108 @@ def test_graph_replay_equals_eager(oa):
 
 
 # --------------------------------------------------------------------------------------------
-# BASELINE configs: cfg2 against the oracle, headline size through size-independent properties
+# BASELINE configs against the oracle; the headline size also through size-independent properties
 # --------------------------------------------------------------------------------------------
-def test_cfg2_against_oracle(oa):
+@pytest.mark.parametrize("mode", ["precise", "fast"])
+def test_cfg2_against_oracle(oa, mode):
     """513 bins x 1000 frames x 4 mics / 2 src, laplace (BASELINE.json configs[1])"""
     X = orc.synth_iid(1000, 513, 4, seed=0)
-    Y, W = oa.overiva(X, n_src=2, n_iter=10, proj_back=False, return_filters=True)
+    oa.set_precision(mode)
+    try:
+        Y, W = oa.overiva(X, n_src=2, n_iter=10, proj_back=False, return_filters=True)
+    finally:
+        oa.set_precision("precise")
     Yr, Wr = orc.overiva_staged(X, n_src=2, n_iter=10, proj_back=False, return_filters=True)
     eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
-    print(f"\n[parity] cfg2 iid 10 its: W err {eW:.2e}  Y err {eY:.2e}")
+    _log(test="cfg2", fixture="T1000F513M4K2 iid", model="laplace", n_iter=10, input="c64", mode=mode, W_vs_c128=eW, Y_vs_c128=eY)
+    print(f"\n[parity] cfg2 iid 10 its {mode}: W err {eW:.2e}  Y err {eY:.2e}")
     assert eW < TOL and eY < TOL
 
 
-def test_cfg2_mixture_against_oracle(oa):
+@pytest.mark.parametrize("mode", ["precise", "fast"])
+def test_cfg2_mixture_against_oracle(oa, mode):
     X = orc.synth_mixture(1000, 513, 4, 2, seed=1)
-    Y, W = oa.overiva(X, n_src=2, n_iter=10, proj_back=False, return_filters=True)
+    oa.set_precision(mode)
+    try:
+        Y, W = oa.overiva(X, n_src=2, n_iter=10, proj_back=False, return_filters=True)
+    finally:
+        oa.set_precision("precise")
     Yr, Wr = orc.overiva_staged(X, n_src=2, n_iter=10, proj_back=False, return_filters=True)
-    eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
-    # floor: the reference's own complex64 arithmetic on this input
     _, Wf = orc.overiva_faithful(X, n_src=2, n_iter=10, proj_back=False, return_filters=True)
-    floor = orc.rel_err(Wf, Wr)
-    print(f"\n[parity] cfg2 mixture 10 its: W err {eW:.2e}  Y err {eY:.2e}  (reference c64 floor {floor:.2e})")
-    assert eY < 5e-5 and eW < max(5e-5, 3 * floor)
+    floor = orc.rel_err(Wf, Wr)          # the reference's own complex64 arithmetic on this input
+    eW, eY, e64 = orc.rel_err(W, Wr), orc.rel_err(Y, Yr), orc.rel_err(W, Wf)
+    _log(test="cfg2", fixture="T1000F513M4K2 mixture", model="laplace", n_iter=10, input="c64", mode=mode, W_vs_c128=eW,
+         Y_vs_c128=eY, W_vs_ref_c64=e64, ref_c64_floor=floor)
+    print(f"\n[parity] cfg2 mixture 10 its {mode}: W err {eW:.2e}  Y err {eY:.2e}, vs reference-c64 {e64:.2e} (floor {floor:.2e})")
+    if mode == "precise":
+        assert eW < TOL and eY < TOL and e64 < max(TOL, 1.5 * floor)
+    else:
+        assert eW < max(TOL, FAST_FLOORS * floor)
 
 
-def test_headline_size_against_oracle(oa):
+@pytest.mark.parametrize("mode", ["precise", "fast"])
+def test_headline_size_against_oracle(oa, mode):
     """2048 x 4000 x 8 / 2 (BASELINE.json configs[2]) end to end against the oracle's reference-faithful form
     (the reference's own arithmetic: complex64 data, float64 activations) for a few iterations."""
     T, F, M, K = 4000, 2048, 8, 2
     X = orc.synth_iid(T, F, M, seed=0)
-    Y, W = oa.overiva(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
+    oa.set_precision(mode)
+    try:
+        Y, W = oa.overiva(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
+    finally:
+        oa.set_precision("precise")
     Yr, Wr = orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
     eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
-    print(f"\n[parity] headline shape iid 3 its vs reference-faithful c64: W err {eW:.2e}  Y err {eY:.2e}")
+    _log(test="headline", fixture="T4000F2048M8K2 iid", model="laplace", n_iter=3, input="c64", mode=mode, W_vs_ref_c64=eW,
+         Y_vs_ref_c64=eY)
+    print(f"\n[parity] headline shape iid 3 its {mode} vs reference-faithful c64: W err {eW:.2e}  Y err {eY:.2e}")
+    assert eW < TOL and eY < TOL
+
+
+@pytest.mark.parametrize("model", ["laplace", "gauss"])
+def test_shard_size_mixture_20_iterations(oa, model):
+    """256 bins x 4000 frames x 8 mics / 2 src (one rank's share of the headline shape at 8 GPUs), mixture-like
+    input, 20 iterations: against the reference-faithful complex64 oracle (the target for complex64 input) and the
+    complex128 one"""
+    T, F, M, K = 4000, 256, 8, 2
+    X = orc.synth_mixture(T, F, M, K, seed=11)
+    Y, W = oa.overiva(X, n_src=K, n_iter=20, proj_back=False, model=model, return_filters=True)
+    _, W128 = orc.overiva_staged(X, n_src=K, n_iter=20, proj_back=False, model=model, return_filters=True)
+    _, W64 = orc.overiva_faithful(X, n_src=K, n_iter=20, proj_back=False, model=model, return_filters=True)
+    floor = orc.rel_err(W64, W128)
+    e128, e64 = orc.rel_err(W, W128), orc.rel_err(W, W64)
+    eY = orc.rel_err(Y, _demix(X, W128))
+    oa.set_precision("fast")
+    try:
+        _, Wfast = oa.overiva(X, n_src=K, n_iter=20, proj_back=False, model=model, return_filters=True)
+    finally:
+        oa.set_precision("precise")
+    efast = orc.rel_err(Wfast, W128)
+    _log(test="shard20", fixture="T4000F256M8K2 mixture", model=model, n_iter=20, input="c64", mode="precise", W_vs_c128=e128,
+         Y_vs_c128=eY, W_vs_ref_c64=e64, ref_c64_floor=floor)
+    _log(test="shard20", fixture="T4000F256M8K2 mixture", model=model, n_iter=20, input="c64", mode="fast", W_vs_c128=efast,
+         ref_c64_floor=floor)
+    print(f"\n[parity] 256x4000x8 mixture {model} 20 its: precise W vs c128 {e128:.2e}, vs reference-c64 {e64:.2e} "
+          f"(floor {floor:.2e}), Y {eY:.2e}; fast W vs c128 {efast:.2e}")
+    assert e64 < max(TOL, 1.5 * floor) and e128 < max(TOL, 0.5 * floor) and eY < max(TOL, 0.5 * floor)
+    assert efast < max(TOL, FAST_FLOORS * floor)
+
+
+@pytest.mark.parametrize("mode", ["precise", "fast"])
+def test_cfg5_shape_full_frame_axis(oa, mode):
+    """BASELINE.json configs[4] shape at full T with few bins: 8 bins x 4000 frames x 16 mics / 16 src -- the
+    multi-split matrix-core covariance (frame chains across 8 splits), the MFMA power pass and the 16x16 solve"""
+    T, F, M, K = 4000, 8, 16, 16
+    X = orc.synth_iid(T, F, M, seed=5)
+    oa.set_precision(mode)
+    try:
+        Y, W = oa.overiva(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
+    finally:
+        oa.set_precision("precise")
+    Yr, Wr = orc.overiva_staged(X, n_src=K, n_iter=3, proj_back=False, return_filters=True)
+    eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
+    _log(test="cfg5", fixture="T4000F8M16K16 iid", model="laplace", n_iter=3, input="c64", mode=mode, W_vs_c128=eW, Y_vs_c128=eY)
+    print(f"\n[parity] cfg5 shape (8 bins) iid 3 its {mode}: W err {eW:.2e}  Y err {eY:.2e}")
     assert eW < TOL and eY < TOL
 
 
@@ -424,6 +578,7 @@ def test_two_plans_are_independent_and_no_leak(oa):
     Yb = oa.overiva(Xb, n_src=1, n_iter=4, proj_back=False)
     pa = oa.Plan(128, 40, 4, 2)
     pb = oa.Plan(96, 33, 3, 1)
+    pa.set_precision("precise"); pb.set_precision("precise")      # what overiva() used above
     pa.set_x(Xa); pb.set_x(Xb)
     pa.covariance(); pb.covariance()
     pa.set_w(None); pb.set_w(None)

@@ -7,7 +7,7 @@ CPU only.
 import numpy as np
 import pytest
 
-from conftest import chaotic
+from conftest import chaotic, need
 from oracle import overiva_oracle as orc
 
 MODELS = ("laplace", "gauss")
@@ -25,6 +25,7 @@ def _case(g):
 @pytest.mark.parametrize("n_iter", (0, 1, 2, 5, 20))
 def test_faithful_c128_W(golden, model, n_iter):
     X, K = _case(golden)
+    need(golden, f"W_c128_{model}_{n_iter}")
     if chaotic(golden, model, n_iter):
         pytest.skip("reference is ill-conditioned here (see conftest.chaotic)")
     Y, W = orc.overiva_faithful(X.astype(np.complex128), n_src=K, n_iter=n_iter, proj_back=False,
@@ -32,7 +33,7 @@ def test_faithful_c128_W(golden, model, n_iter):
     ref = golden[f"W_c128_{model}_{n_iter}"]
     assert W.shape == ref.shape and W.dtype == ref.dtype
     assert orc.rel_err(W, ref) < TOL128
-    if n_iter == 20:
+    if n_iter == 20 and f"Y_c128_{model}_20" in golden:
         assert orc.rel_err(Y, golden[f"Y_c128_{model}_20"]) < TOL128
 
 
@@ -41,6 +42,8 @@ def test_faithful_c128_W(golden, model, n_iter):
 def test_faithful_c64_W(golden, model, n_iter):
     X, K = _case(golden)
     key = f"c64_{model}_{n_iter}"
+    if key not in set(golden["nonfinite"].tolist()):
+        need(golden, f"W_{key}")
     if key in set(golden["nonfinite"].tolist()):
         pytest.skip("the reference itself diverged to NaN on this input in complex64")
     if chaotic(golden, model, n_iter):
@@ -66,13 +69,14 @@ def test_staged_matches_reference(golden, model):
         Y, W = orc.overiva_staged(X.astype(np.complex128), n_src=K, n_iter=n_iter, proj_back=False,
                                   model=model, return_filters=True)
         assert orc.rel_err(W, golden[f"W_c128_{model}_{n_iter}"]) < 1e-8
-        if n_iter == 20:
+        if n_iter == 20 and f"Y_c128_{model}_20" in golden:
             assert orc.rel_err(Y, golden[f"Y_c128_{model}_20"]) < 1e-8
 
 
 @pytest.mark.parametrize("model", MODELS)
 def test_proj_back_and_callback(golden, model):
     X, K = _case(golden)
+    need(golden, f"Ypb_c128_{model}_12")
     if chaotic(golden, model, 12):
         pytest.skip("reference is ill-conditioned here (see conftest.chaotic)")
     got = []
@@ -89,6 +93,7 @@ def test_proj_back_and_callback(golden, model):
 
 def test_warm_start_default_nsrc_and_eig(golden):
     X, K = _case(golden)
+    need(golden, "W0")
     X = X.astype(np.complex128)
     _, W = orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=False, W0=golden["W0"], return_filters=True)
     assert orc.rel_err(W, golden["W_w0_c128_laplace_3"]) < TOL128
@@ -103,8 +108,13 @@ def test_warm_start_default_nsrc_and_eig(golden):
 def test_auxiva_pca(golden):
     X, K = _case(golden)
     Y = orc.auxiva_pca_faithful(X.astype(np.complex128), n_src=K, n_iter=5, proj_back=True, model="laplace")
-    assert Y.shape == golden["Ypca_c128_laplace_5"].shape
-    assert orc.rel_err(Y, golden["Ypca_c128_laplace_5"]) < 1e-7
+    if "Ypca_c128_laplace_5" in golden:
+        assert Y.shape == golden["Ypca_c128_laplace_5"].shape
+        assert orc.rel_err(Y, golden["Ypca_c128_laplace_5"]) < 1e-7
+    else:                                    # F >= 64 fixtures keep frame 0 of the outputs only
+        assert orc.rel_err(Y[0], golden["Ypca_frame0_c128_laplace_5"]) < 1e-7
+        Yp = orc.overiva_faithful(X.astype(np.complex128), n_src=K, n_iter=12, proj_back=True, model="laplace")
+        assert orc.rel_err(Yp[0], golden["Ypb_frame0_c128_laplace_12"]) < TOL128
     with pytest.raises(KeyError):            # auxiva_pca.py:86 pops 'proj_back' unconditionally
         orc.auxiva_pca_faithful(X.astype(np.complex128), n_src=K, n_iter=1)
 
