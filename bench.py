@@ -29,10 +29,23 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-T, F, M, K = 4000, 2048, 8, 2
 MODEL = "laplace"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-WORKLOAD = f"OverIVA {F} bins x {T} frames x {M} mics / {K} src, {MODEL}, complex64 (BASELINE.json configs[2])"
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+# --config: the headline workload (default; the one BASELINE.json's metric is quoted on) and configs[4]
+CONFIGS = {
+    "headline": dict(T=4000, F=2048, M=8, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[2])"),
+    "cfg5": dict(T=4000, F=2048, M=16, K=16, name="determined AuxIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[4])"),
+}
+T, F, M, K = 4000, 2048, 8, 2
+WORKLOAD = CONFIGS["headline"]["name"].format(T=T, F=F, M=M, K=K)
+
+
+def select_config(name):
+    global T, F, M, K, WORKLOAD
+    c = CONFIGS[name]
+    T, F, M, K = c["T"], c["F"], c["M"], c["K"]
+    WORKLOAD = c["name"].format(T=T, F=F, M=M, K=K)
 
 
 def cov_algorithmic_bytes(t, f, m, k):
@@ -45,12 +58,14 @@ def measured_traffic(kernel_key):
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction; see
     profiles/r01_pmc_hbm_traffic.json).  PMC counters need rocprofv3 around the process, so they cannot
     be sampled from inside a plain bench run; None when the profile is absent."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch"]), os.path.relpath(path, REPO)
-    except Exception:
-        return None, None
+    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        path = os.path.join(REPO, "profiles", name)
+        try:
+            with open(path) as f:
+                return float(json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch"]), os.path.relpath(path, REPO)
+        except Exception:
+            continue
+    return None, None
 
 
 def synth_x_device(torch, device, f0, f1):
@@ -113,11 +128,31 @@ def cpu_baseline():
                "sample": f"{fs1} of {F} bins, one BLAS thread, {per1:.3f} s per iteration on the sample"}
     except Exception:
         pass
+    # `cores` = BLAS threads the run was ALLOWED to use; the batched (M x T)(T x M) products of overiva.py:179 do
+    # not thread in OpenBLAS (one thread gives the same rate, see single_thread), so it is effectively one core
     return {"value": (1.0 / per_iter) * fs / F, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "effective_cores": 1 if one and one["value"] > 0.8 * (1.0 / per_iter) * fs / F else threads,
             "cpu": _cpu_model(), "host_cpus": os.cpu_count(), "single_thread": one,
             "sample": f"oracle.overiva_faithful (NumPy, complex64 in / float64 r like overiva.py) on {fs} of {F} bins x "
                       f"{T} frames x {M} mics / {K} src, iterations 2-5, scaled by {fs}/{F}; "
                       f"{per_iter:.3f} s per iteration on the sample"}
+
+
+def _time_plan(plan, args):
+    """W untimed warm-up iterations, then exactly K timed ones bracketed by synchronisation; then the same K again
+    with every kernel bracketed by HIP events on the plan's stream"""
+    import torch
+
+    plan.iterate(args.warmup)
+    plan.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan.iterate(args.steps)
+    plan.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    total_ms, stages = plan.iterate_timed(args.steps, per_kernel=True)
+    return dt, total_ms, stages
 
 
 def run_single(args):
@@ -129,36 +164,59 @@ def run_single(args):
     torch.cuda.set_device(dev)
     X = synth_x_device(torch, dev, 0, F)
     torch.cuda.synchronize()
-    plan = oa.Plan(T, F, M, K, MODEL, device=0)
-    plan.set_x_device(X.data_ptr(), keepalive=X)
-    plan.covariance()
-    plan.set_w(None)
-    if args.graph:
-        plan.use_graph(True)
-    plan.iterate(args.warmup)
-    plan.sync()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    plan.iterate(args.steps)
-    plan.sync()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    # the same K steps again with every kernel bracketed by HIP events on the plan's stream
-    total_ms, stages = plan.iterate_timed(args.steps, per_kernel=True)
+
+    def make(mode):
+        plan = oa.Plan(T, F, M, K, MODEL, device=0)
+        plan.set_precision(mode)
+        plan.set_x_device(X.data_ptr(), keepalive=X)
+        plan.covariance()
+        plan.set_w(None)
+        if args.graph:
+            plan.use_graph(True)
+        return plan
+
+    plan = make(args.precision)
+    dt, total_ms, stages = _time_plan(plan, args)
     W = plan.get_w()
     assert np.all(np.isfinite(W))
-    cov_ms = stages["weighted_cov"] / args.steps
-    bytes_cov = cov_algorithmic_bytes(T, F, M, K)
-    achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic("cov_dma_kernel<8, 2>")
-    roofline = {"bound": "hbm", "kernel": "cov_dma_kernel<8,2> (weighted spatial covariance of both sources in one pass, overiva.py:179)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
-                "stage_ms_per_step": {k: v / args.steps for k, v in stages.items()},
-                "event_timed_ms_per_step": total_ms / args.steps, "cov_splits": plan.cov_splits()}
+    splits = plan.cov_splits()
     plan.close()
+    cov_ms = stages["weighted_cov"] / args.steps
+    per_step = {k: v / args.steps for k, v in stages.items()}
+    if M <= 8:
+        bytes_cov = cov_algorithmic_bytes(T, F, M, K)
+        achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
+        kname = f"cov_dma_kernel<{M}, {min(K, 2)}>" if args.precision == "fast" else f"cov_gram_kernel<{min(K, 2)}>"
+        traffic, traffic_src = measured_traffic(kname)
+        roofline = {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, overiva.py:179)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_cov}
+        # the whole iteration against the same roofline: X is read twice (demix/power pass, covariance pass)
+        bytes_iter = bytes_cov + 8 * T * F * M + 4 * T * K * (1 + F // 64)
+        roofline["iteration"] = {"algorithmic_bytes": bytes_iter, "achieved": bytes_iter / (total_ms / args.steps * 1e-3) / 1e9,
+                                 "frac": bytes_iter / (total_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    else:
+        naive = 8.0 * K * M * M * T * F            # complex MACs counted as 8 real flops
+        issued = 6.0 * K * M * M * T * F           # what the planar form issues: 3 MFMAs of 16x16x4 per 4 frames and source
+        roofline = {"bound": "fp32-mfma", "kernel": "cov_mfma16_kernel<float, 16> (planar v_mfma_f32_16x16x4_f32, overiva.py:179)",
+                    "achieved": issued / (cov_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": issued / (cov_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "issued_flops_per_launch": issued, "naive_complex_flops_per_launch": naive,
+                    "naive_complex_tflops": naive / (cov_ms * 1e-3) / 1e12,
+                    "note": "achieved/frac count ISSUED matrix-core flops; the naive-complex figure is algorithmic speed only"}
+    roofline.update({"avg_launch_ms": cov_ms, "stage_ms_per_step": per_step, "event_timed_ms_per_step": total_ms / args.steps,
+                     "cov_splits": splits})
     out = result_line(args, 1, dt)
     out["roofline"] = roofline
+    if not args.no_other_mode:
+        # the other arithmetic mode on the same workload, same timing protocol (reported next to the metric; the
+        # drop-in overiva() defaults to "precise", the metric's float32 tolerance is met by "fast" on this input)
+        other = "precise" if args.precision == "fast" else "fast"
+        plan = make(other)
+        dt2, total2, stages2 = _time_plan(plan, args)
+        plan.close()
+        out["other_mode"] = {"precision": other, "value": args.steps / dt2, "unit": "iterations/s", "ms_per_step": dt2 / args.steps * 1e3,
+                             "stage_ms_per_step": {k: v / args.steps for k, v in stages2.items()}}
     out["cpu_baseline"] = cpu_baseline() if not args.no_cpu else None
     if out["cpu_baseline"]:
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
@@ -184,7 +242,7 @@ def run_sharded(args):
     f0, f1 = b[rank], b[rank + 1]
     X = synth_x_device(torch, dev, f0, f1)
     torch.cuda.synchronize()
-    eng = HipEngine(T, f1 - f0, M, K, MODEL, F, local)
+    eng = HipEngine(T, f1 - f0, M, K, MODEL, F, local, precision=args.precision)
     stream = eng.stream
     with eng.stream_ctx():
         eng.set_x_device(X.data_ptr(), keepalive=X)
@@ -202,6 +260,23 @@ def run_sharded(args):
         for _ in range(args.warmup):
             step()
         stream.synchronize()
+        # per-rank stage breakdown (eager, events on the shared stream): power pass | all-gather | activation +
+        # covariance + update
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        acc = [0.0, 0.0, 0.0]
+        nb = 5
+        for _ in range(nb):
+            ev[0].record(stream)
+            eng.power()
+            ev[1].record(stream)
+            dist.all_gather_into_tensor(p_all, p_local)
+            ev[2].record(stream)
+            eng.update(p_all)
+            ev[3].record(stream)
+            stream.synchronize()
+            for i in range(3):
+                acc[i] += ev[i].elapsed_time(ev[i + 1]) / nb
+        breakdown = {"power_ms": acc[0], "all_gather_ms": acc[1], "activation_cov_update_ms": acc[2]}
         graph = None
         spg = 8            # iterations per captured graph (kernels + the RCCL all-gather)
         # Capturing RCCL collectives in a graph was verified with one rank only (this pool has 1-GPU boxes), so
@@ -238,15 +313,19 @@ def run_sharded(args):
     W = eng.get_w()
     assert np.all(np.isfinite(W))
     eng.close()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {"rank": rank, "bins": [f0, f1], **breakdown})
     out = result_line(args, world, float(tmax.item()))
     out["config"]["graph"] = graph is not None
+    out["ranks"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "per_rank_stage_ms": gathered,
+                    "message_bytes_per_rank": int(p_local.numel() * 4)}
     dist.destroy_process_group()
     return out if rank == 0 else None
 
 
 def result_line(args, n_gpus, seconds):
     return {
-        "metric": "AuxIVA iterations/sec (2048 bins x 4000 frames x 8 mics)",
+        "metric": f"AuxIVA iterations/sec ({F} bins x {T} frames x {M} mics)",
         "value": args.steps / seconds,
         "unit": "iterations/s",
         "n_gpus": n_gpus,
@@ -256,9 +335,11 @@ def result_line(args, n_gpus, seconds):
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.precision == "fast" else "f64",
         "data": "synthetic",
         "config": {"workload": WORKLOAD, "bins": F, "frames": T, "mics": M, "sources": K, "model": MODEL,
+                   "precision": args.precision + (" (float32 everywhere; overiva() defaults to 'precise', see other_mode)"
+                                                  if args.precision == "fast" else " (float64 covariance accumulation + per-bin algebra)"),
                    "parallelism": f"bins sharded over {n_gpus} GPU(s), one RCCL all-gather of (T,K) f32 per iteration"
                    if n_gpus > 1 else "single GPU", "graph": bool(args.graph)},
     }
@@ -272,9 +353,15 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="0: eager; 1 (default): hipGraph replay on a single GPU, eager when sharded; 2: graph also when sharded")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="headline",
+                    help="headline: BASELINE.json configs[2] (the metric's workload); cfg5: configs[4], 16 mics / 16 sources")
+    ap.add_argument("--precision", choices=["fast", "precise"], default="fast",
+                    help="arithmetic of the timed run (default fast = float32, the metric's dtype); the other mode is timed too")
+    ap.add_argument("--no-other-mode", action="store_true", help="do not also time the other arithmetic mode")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (exercises RCCL + graph capture on 1 GPU)")
     args = ap.parse_args()
+    select_config(args.config)
     if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_sharded:
         out = run_sharded(args)
     else:

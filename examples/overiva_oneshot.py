@@ -54,7 +54,7 @@ def sir_db(W, images):
     return best
 
 
-if __name__ == "__main__":
+def parse_args(argv=None):
     ap = argparse.ArgumentParser(description="Demonstration of blind source extraction using overdetermined IVA.")
     ap.add_argument("--no_cb", action="store_true", help="Removes callback function")
     ap.add_argument("-a", "--algo", type=str, default=algo_choices[0], choices=algo_choices, help="Chooses BSS method to run")
@@ -65,42 +65,65 @@ if __name__ == "__main__":
     ap.add_argument("-n", "--n_iter", type=int, default=51, help="Number of iterations")
     ap.add_argument("--frames", type=int, default=160, help="STFT frames of the synthetic scene")
     ap.add_argument("--seed", type=int, default=0)
-    args = ap.parse_args()
-    assert args.srcs <= args.mics, "More sources than microphones is not supported"
+    args = ap.parse_args(argv)
+    assert args.srcs <= args.mics, "More sources than microphones is not supported"      # overiva_oneshot.py:118
+    return args
 
-    import overiva_amd
+
+def separate(args, X_mics, overiva, auxiva_pca, callback):
+    """the dispatch of overiva_oneshot.py:301-330, argument for argument (auxiva: all channels, no n_src and no
+    init_eig; auxiva_pca: n_src, no init_eig; overiva: n_src and init_eig)"""
+    if args.algo == "auxiva":                          # overiva_oneshot.py:303-309
+        return overiva(X_mics, n_iter=args.n_iter, proj_back=True, model=args.dist, callback=callback)
+    if args.algo == "auxiva_pca":                      # overiva_oneshot.py:312-319
+        return auxiva_pca(X_mics, n_src=args.srcs, n_iter=args.n_iter, proj_back=True, model=args.dist, callback=callback)
+    return overiva(X_mics, n_src=args.srcs, n_iter=args.n_iter, proj_back=True, model=args.dist,   # :322-330
+                   init_eig=(args.init == init_choices[1]), callback=callback)
+
+
+def output_sir(Y, X_mics, images, n_keep):
+    """SIR of the n_keep strongest outputs (the reference re-orders by power, overiva_oneshot.py:387-389).  The
+    outputs are linear in the mixture per bin: the demixing of each bin is recovered by least squares from (X, Y),
+    then applied to the known source images."""
+    order = np.argsort(np.sum(np.abs(Y) ** 2, axis=(0, 1)))[::-1][:n_keep]
+    T, F, M = X_mics.shape
+    W = np.empty((F, M, n_keep), dtype=np.complex128)
+    for f in range(F):
+        G, *_ = np.linalg.lstsq(X_mics[:, f, :], Y[:, f, order], rcond=None)     # Y = X G, G = conj(W)
+        W[f] = np.conj(G)
+    return sir_db(W, images)
+
+
+def run(argv=None, verbose=True):
+    """run the driver; returns what a test needs (arguments, scene, outputs, callback trace, timings, SIRs)"""
+    args = parse_args(argv)
     from overiva_amd import auxiva_pca, overiva
 
     framesize = 4096                                  # overiva_oneshot.py:156
     n_freq = framesize // 2 + 1
     X_mics, images = synthetic_scene(args.mics, args.srcs, args.frames, n_freq, args.seed)
-    print(f"scene: {args.frames} frames x {n_freq} bins x {args.mics} mics, {args.srcs} targets, dtype {X_mics.dtype}")
-
+    if verbose:
+        print(f"scene: {args.frames} frames x {n_freq} bins x {args.mics} mics, {args.srcs} targets, dtype {X_mics.dtype}")
     trace = []
 
-    def convergence_callback(Y):
+    def convergence_callback(Y):                      # overiva_oneshot.py:263-284 (metric instead of bss_eval)
         trace.append(float(np.mean(np.abs(Y) ** 2)))
 
     cb = None if args.no_cb else convergence_callback
-    init_eig = args.init == init_choices[1]
-
-    t_begin = time.perf_counter()
-    if args.algo == "auxiva":                          # overiva_oneshot.py:303-309 (no n_src: determined)
-        Y, W = overiva(X_mics, n_iter=args.n_iter, proj_back=True, model=args.dist, init_eig=init_eig,
-                       return_filters=True, callback=cb)
-    elif args.algo == "auxiva_pca":                    # overiva_oneshot.py:312-319
-        Y = auxiva_pca(X_mics, n_src=args.srcs, n_iter=args.n_iter, proj_back=True, model=args.dist, callback=cb)
-        W = None
-    else:                                              # overiva_oneshot.py:322-330
-        Y, W = overiva(X_mics, n_src=args.srcs, n_iter=args.n_iter, proj_back=True, model=args.dist,
-                       init_eig=init_eig, return_filters=True, callback=cb)
+    t_begin = time.perf_counter()                     # overiva_oneshot.py:298
+    Y = separate(args, X_mics, overiva, auxiva_pca, cb)
     t_end = time.perf_counter()
-    print("Time for BSS: {:.2f} s".format(t_end - t_begin))   # overiva_oneshot.py:366-368
-    print(f"output {Y.shape} {Y.dtype}; callback fired {len(trace)} times")
-    if W is not None:
-        if W.shape[2] > args.srcs:                     # keep the strongest outputs, overiva_oneshot.py:387-389
-            order = np.argsort(np.sum(np.abs(Y) ** 2, axis=(0, 1)))[::-1][: args.srcs]
-            W = W[:, :, order]
-        W0 = np.zeros_like(W)
-        W0[:, : W.shape[2], :] = np.eye(W.shape[2])
-        print(f"SIR of the demixed bins: {sir_db(W, images):.1f} dB (identity demixing: {sir_db(W0, images):.1f} dB)")
+    sir_out = output_sir(Y, X_mics, images, args.srcs)
+    W0 = np.zeros((n_freq, args.mics, args.srcs), dtype=np.complex128)
+    W0[:, : args.srcs, :] = np.eye(args.srcs)
+    sir_in = sir_db(W0, images)
+    if verbose:
+        print("Time for BSS: {:.2f} s".format(t_end - t_begin))   # overiva_oneshot.py:366-368
+        print(f"output {Y.shape} {Y.dtype}; callback fired {len(trace)} times")
+        print(f"SIR of the {args.srcs} strongest outputs: {sir_out:.1f} dB (first {args.srcs} microphones: {sir_in:.1f} dB)")
+    return {"args": args, "X": X_mics, "images": images, "Y": Y, "trace": trace, "seconds": t_end - t_begin,
+            "sir_out": sir_out, "sir_in": sir_in}
+
+
+if __name__ == "__main__":
+    run()

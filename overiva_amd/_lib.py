@@ -73,6 +73,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own copy of the HIP runtime.  Two HIP runtimes in one process do not share
+    # the GPU: whichever initialises second reports "No HIP GPUs are available".  When torch is installed (the
+    # multi-GPU driver, bench.py and the tests use it for process groups and device tensors) it is imported
+    # first, so that its runtime is the one already loaded when liboveriva_hip.so resolves libamdhip64.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: the HIP extension is not built.  Run `python -m overiva_amd.build` "

@@ -6,25 +6,28 @@ namespace oiva {
 namespace {
 
 // Source activation, reference overiva.py:152-155:
-//   R[e] = 2 sqrt(p) (laplace) | p / F_total (gauss), p = sum over parts in part order (bin batch or rank
-//   order), e = t*K + k.  kActLanes lanes share one element: lane l adds parts l, l+8, ...; a fixed
-//   shuffle tree adds the lanes.  The scale normalisation (gamma, overiva.py:158-173) is applied by the
-//   consumers (covariance and update kernels) through block_gamma() / activation_weight().
-constexpr int kActLanes = 8;
+//   R[e] = 2 sqrt(p) (laplace) | p / F_total (gauss), p = sum over parts in part order (bin batch, or rank then
+//   batch), e = t*K + k.  One thread per element adds the parts strictly in order, so parts that are all zero
+//   (the padding that equalises the ranks' messages in a bin-sharded run) change nothing: a sharded run whose
+//   shard boundaries fall on 64-bin batches gets the same bits as the single-GPU run.  The loads of a group of 8
+//   parts are issued together; the adds are sequential.  The scale normalisation (gamma, overiva.py:158-173) is
+//   applied by the consumers (covariance and update kernels) through block_gamma() / activation_weight().
 __global__ __launch_bounds__(kBlock) void activation_kernel(const float* __restrict__ parts, int nparts,
                                                            float* __restrict__ R, long long n, int model,
                                                            float inv_f_total) {
-    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    const long long e = gid / kActLanes;
-    const int l = (int)(gid % kActLanes);
+    const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n) return;
     float p = 0.f;
-    if (e < n) {
-#pragma unroll 4
-        for (int i = l; i < nparts; i += kActLanes) p += parts[(size_t)i * n + e];
-    }
+    int i = 0;
+    for (; i + 8 <= nparts; i += 8) {
+        float v[8];
 #pragma unroll
-    for (int off = 1; off < kActLanes; off <<= 1) p += __shfl_xor(p, off, kActLanes);
-    if (e < n && l == 0) R[e] = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(p) : p * inv_f_total;
+        for (int u = 0; u < 8; ++u) v[u] = parts[(size_t)(i + u) * n + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p += v[u];
+    }
+    for (; i < nparts; ++i) p += parts[(size_t)i * n + e];
+    R[e] = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(p) : p * inv_f_total;
 }
 
 template <typename IN>
@@ -71,8 +74,7 @@ __global__ __launch_bounds__(kBlock) void unpack_herm_kernel(const double* __res
 hipError_t launch_activation(hipStream_t s, const float* parts, int nparts, float* R, int T, int K, int model,
                              int F_total) {
     const long long n = (long long)T * K;
-    const long long threads = n * kActLanes;
-    hipLaunchKernelGGL(activation_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, parts,
+    hipLaunchKernelGGL(activation_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, parts,
                        nparts, R, n, model, 1.f / (float)F_total);
     return hipGetLastError();
 }

@@ -544,7 +544,8 @@ int oiva_plan_power_buffer(oiva_plan* p, int parts_per_rank, void** parts_dev, l
         if (p->Ppart) HIP_TRY(hipFree(p->Ppart));
         p->Ppart = nullptr;
         HIP_TRY(hipMalloc(&p->Ppart, part * parts_per_rank));
-        HIP_TRY(hipMemset(p->Ppart, 0, part * parts_per_rank));   // parts beyond nb stay zero
+        // parts beyond nb stay zero; on the plan's own stream, so that it is ordered before the next power pass
+        HIP_TRY(hipMemsetAsync(p->Ppart, 0, part * parts_per_rank, p->stream));
         p->ppart_alloc = parts_per_rank;
     }
     *parts_dev = p->Ppart;

@@ -7,7 +7,7 @@ import bench
 
 
 def test_result_line_fields():
-    args = types.SimpleNamespace(steps=50, warmup=5, graph=1)
+    args = types.SimpleNamespace(steps=50, warmup=5, graph=1, precision="fast")
     line = bench.result_line(args, 1, 0.0125)
     json.dumps(line)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -17,7 +17,13 @@ def test_result_line_fields():
     assert line["higher_is_better"] is True and line["scaling"] == "strong" and line["vs_baseline"] is None
     assert line["dtype"] == "f32" and line["data"] == "synthetic"
     assert "workload" in line["config"] and "model" in line["config"] and line["n_gpus"] == 1
-    assert "2048" in line["metric"] and "4000" in line["metric"]
+    assert "2048" in line["metric"] and "4000" in line["metric"] and "8 mics" in line["metric"]
+    assert line["config"]["precision"].startswith("fast")
+
+
+def test_cfg5_is_a_config_not_the_default():
+    assert bench.CONFIGS["headline"]["M"] == 8 and bench.CONFIGS["cfg5"]["M"] == 16 and bench.CONFIGS["cfg5"]["K"] == 16
+    assert (bench.T, bench.F, bench.M, bench.K) == (4000, 2048, 8, 2)
 
 
 def test_algorithmic_bytes_match_survey():
