@@ -109,7 +109,6 @@ __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ 
                                                      ACC* __restrict__ Vpart, int T, int F, int K, int tc) {
     constexpr int NA = M * M;
     __shared__ ACC lds[kChunk * kLdsStride];
-    __shared__ double gscratch[kWaves];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -131,8 +130,9 @@ __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ 
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
             const int k = k0 + kk;
-            const double gamma = block_gamma(R, T, K, k < K ? k : K - 1, gscratch);
-            if (!(raw & 1)) ginv[kk] = 1. / gamma;
+            if (raw & 1) continue;          // test hook: R holds the final reciprocal weights
+            const double gamma = gamma_of(R, T, K, k < K ? k : K - 1);
+            ginv[kk] = 1. / gamma;
             if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && k < K && wscale != nullptr)
                 wscale[k] = model == OIVA_MODEL_LAPLACE ? (float)gamma : (float)sqrt(gamma);   // overiva.py:163 / :167
         }
@@ -246,7 +246,6 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
     constexpr int STAGE = PIECES * 64;                  // float4 per stage per wave
     static_assert(M % 2 == 0 && (PIECES == 2 || PIECES == 4), "LDS-DMA path: M in {4, 8}");
     __shared__ float4 ring[kWaves * kDmaStages * STAGE];
-    __shared__ double gscratch[kWaves];
     static_assert(sizeof(float4) * kWaves * kDmaStages * STAGE >= sizeof(float) * kChunk * kLdsStride,
                   "reduction scratch aliases the ring");
 
@@ -318,13 +317,14 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
     issue(0, 0);
     issue(1, 1);
     issue(2, 2);
-    // scale normalisation of the activations (overiva.py:158-159), computed while the first three steps
-    // are on their way from HBM
+    // scale normalisation of the activations (overiva.py:158-159) while the first three steps are on their way
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) {
         const int k = k0 + kk;
-        const float gamma = (float)block_gamma(R, T, K, k < K ? k : K - 1, gscratch);
-        ginv[kk] = (raw & 1) ? 1.f : 1.f / gamma;
+        ginv[kk] = 1.f;
+        if (raw & 1) continue;              // test hook: R holds the final reciprocal weights
+        const float gamma = (float)gamma_of(R, T, K, k < K ? k : K - 1);
+        ginv[kk] = 1.f / gamma;
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && k < K && wscale != nullptr)
             wscale[k] = model == OIVA_MODEL_LAPLACE ? gamma : sqrtf(gamma);   // overiva.py:163 / :167
     }

@@ -105,7 +105,6 @@ __global__ __launch_bounds__(kBlock, 3) void cov_gram_kernel(const float* __rest
     static_assert(NW == 2 || NW == 4, "a frame's weights are one LDS read");
     __shared__ __attribute__((aligned(16))) float ring[kWaves][kStages][kStageFloats];
     __shared__ __attribute__((aligned(16))) double wtab[kTabFrames * KC];   // weights of this workgroup's frames
-    __shared__ double gscratch[kWaves];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -143,9 +142,9 @@ __global__ __launch_bounds__(kBlock, 3) void cov_gram_kernel(const float* __rest
     for (int kk = 0; kk < KC; ++kk) {
         const int k = k0 + kk;
         double ginv = 1.0;
-        if (!unit) {
-            const double gamma = block_gamma(R, T, K, k < K ? k : K - 1, gscratch);
-            if (!(raw & 1)) ginv = 1.0 / gamma;
+        if (!unit && !(raw & 1)) {
+            const double gamma = gamma_of(R, T, K, k < K ? k : K - 1);
+            ginv = 1.0 / gamma;
             if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && k < K && wscale != nullptr)
                 wscale[k] = model == OIVA_MODEL_LAPLACE ? (float)gamma : (float)sqrt(gamma);   // overiva.py:163 / :167
         }

@@ -16,49 +16,22 @@ namespace oiva {
 namespace {
 
 // Final weights w[t,k] = 1 / max(r[t,k] / gamma_k, eps) (overiva.py:158-173) for the matrix-core kernel, which
-// has no VALU slots to spare for the divide.  One workgroup per 256 frames; every workgroup derives all K
-// gamma_k itself in ONE pass over R (fixed order: per-thread strided sums, wave tree, waves in order).
+// has no VALU slots to spare for the divide: one thread per (frame, padded source column).
 constexpr int kMaxK = OIVA_MAX_CHANNELS;
 __global__ __launch_bounds__(kBlock) void weights_kernel(const float* __restrict__ R, float* __restrict__ Wt,
                                                          float* __restrict__ wscale, int model, int raw, int T, int K,
                                                          int Kp) {
-    __shared__ double part[kWaves][kMaxK];
-    double s[kMaxK];
-#pragma unroll
-    for (int k = 0; k < kMaxK; ++k) s[k] = 0.;
-    for (int t = threadIdx.x; t < T; t += kBlock) {
-        const float* row = R + (size_t)t * K;
-#pragma unroll
-        for (int k = 0; k < kMaxK; ++k)
-            if (k < K) s[k] += (double)row[k];
+    const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= (long long)T * Kp) return;
+    const int t = (int)(e / Kp), k = (int)(e - (long long)t * Kp);
+    float w = 0.f;                                      // padding columns: sources that do not exist weigh 0
+    if (k < K) {
+        const float gamma = (raw & 1) ? 1.f : (float)gamma_of(R, T, K, k);
+        w = activation_weight(R[(size_t)t * K + k], 1.f / gamma);
+        if (t == 0 && wscale != nullptr && !(raw & 1))
+            wscale[k] = model == OIVA_MODEL_LAPLACE ? gamma : sqrtf(gamma);   // overiva.py:163 / :167
     }
-#pragma unroll
-    for (int k = 0; k < kMaxK; ++k) {
-        if (k < K) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off, 64);
-            if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = s[k];
-        }
-    }
-    __syncthreads();
-    const int t = blockIdx.x * kBlock + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < kMaxK; ++k) {
-        if (k < Kp) {
-            float w = 0.f;                                  // padding columns: sources that do not exist weigh 0
-            if (k < K) {
-                double g = 0.;
-#pragma unroll
-                for (int wv = 0; wv < kWaves; ++wv) g += part[wv][k];
-                const float gamma = (float)(g / (double)T);
-                const float ginv = (raw & 1) ? 1.f : 1.f / gamma;
-                if (t < T) w = activation_weight(R[(size_t)t * K + k], ginv);
-                if (blockIdx.x == 0 && threadIdx.x == 0 && wscale != nullptr)
-                    wscale[k] = model == OIVA_MODEL_LAPLACE ? gamma : sqrtf(gamma);   // overiva.py:163 / :167
-            }
-            if (t < T) Wt[(size_t)t * Kp + k] = w;
-        }
-    }
+    Wt[e] = w;
 }
 
 template <typename REAL, int KW, bool UNIT>
@@ -187,7 +160,7 @@ hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float
     const int Kp = (K + 15) / 16 * 16;      // padded row stride of the weights (scratch holds T * 16 floats)
     if (!unit) {
         if (Wt == nullptr) return hipErrorInvalidValue;
-        weights_kernel<<<dim3((T + kBlock - 1) / kBlock), dim3(kBlock), 0, s>>>(R, Wt, wscale, model, raw, T, K, Kp);
+        weights_kernel<<<dim3((unsigned)(((long long)T * Kp + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>(R, Wt, wscale, model, raw, T, K, Kp);
     }
     if (f64) return launch_planar<double>(s, X, Wt, Vpart, unit, T, F, M, K, Kp, nsplit, tc);
     return launch_planar<float>(s, X, Wt, Vpart, unit, T, F, M, K, Kp, nsplit, tc);

@@ -6,28 +6,47 @@ namespace oiva {
 namespace {
 
 // Source activation, reference overiva.py:152-155:
-//   R[e] = 2 sqrt(p) (laplace) | p / F_total (gauss), p = sum over parts in part order (bin batch, or rank then
-//   batch), e = t*K + k.  One thread per element adds the parts strictly in order, so parts that are all zero
-//   (the padding that equalises the ranks' messages in a bin-sharded run) change nothing: a sharded run whose
-//   shard boundaries fall on 64-bin batches gets the same bits as the single-GPU run.  The loads of a group of 8
-//   parts are issued together; the adds are sequential.  The scale normalisation (gamma, overiva.py:158-173) is
-//   applied by the consumers (covariance and update kernels) through block_gamma() / activation_weight().
+//   R[t,k] = 2 sqrt(p) (laplace) | p / F_total (gauss), p = sum over parts in part order (bin batch, or rank then
+//   batch).  One thread per frame adds the parts strictly in order, so parts that are all zero (the padding that
+//   equalises the ranks' messages in a bin-sharded run) change nothing: a sharded run whose shard boundaries fall
+//   on 64-bin batches gets the same bits as the single-GPU run.  The loads of a group of 8 parts are issued
+//   together; the adds are sequential.  Each block (kBlock frames of one source) also leaves the float64 sum of its r per
+//   source behind R (rsum_offset_floats): the consumers derive gamma (overiva.py:158) from those few values
+//   (gamma_of) instead of re-reducing the T activations in every workgroup.
 __global__ __launch_bounds__(kBlock) void activation_kernel(const float* __restrict__ parts, int nparts,
-                                                           float* __restrict__ R, long long n, int model,
+                                                           float* __restrict__ R, int T, int K, int model,
                                                            float inv_f_total) {
-    const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (e >= n) return;
-    float p = 0.f;
-    int i = 0;
-    for (; i + 8 <= nparts; i += 8) {
-        float v[8];
+    __shared__ double wsum[kWaves];
+    const int t = blockIdx.x * kBlock + threadIdx.x;      // grid = (blocks of kBlock frames, sources)
+    const int k = blockIdx.y;
+    const size_t n = (size_t)T * K;
+    float r = 0.f;
+    if (t < T) {
+        const size_t e = (size_t)t * K + k;
+        float p = 0.f;
+        int i = 0;
+        for (; i + 8 <= nparts; i += 8) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = parts[(size_t)(i + u) * n + e];
+            for (int u = 0; u < 8; ++u) v[u] = parts[(size_t)(i + u) * n + e];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) p += v[u];
+            for (int u = 0; u < 8; ++u) p += v[u];
+        }
+        for (; i < nparts; ++i) p += parts[(size_t)i * n + e];
+        r = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(p) : p * inv_f_total;
+        R[e] = r;
     }
-    for (; i < nparts; ++i) p += parts[(size_t)i * n + e];
-    R[e] = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(p) : p * inv_f_total;
+    double s = (double)r;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) tot += wsum[w];
+        reinterpret_cast<double*>(R + rsum_offset_floats(T, K))[(size_t)blockIdx.x * K + k] = tot;
+    }
 }
 
 template <typename IN>
@@ -73,9 +92,8 @@ __global__ __launch_bounds__(kBlock) void unpack_herm_kernel(const double* __res
 
 hipError_t launch_activation(hipStream_t s, const float* parts, int nparts, float* R, int T, int K, int model,
                              int F_total) {
-    const long long n = (long long)T * K;
-    hipLaunchKernelGGL(activation_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, parts,
-                       nparts, R, n, model, 1.f / (float)F_total);
+    hipLaunchKernelGGL(activation_kernel, dim3((unsigned)rsum_blocks(T), (unsigned)K), dim3(kBlock), 0, s, parts, nparts, R, T, K,
+                       model, 1.f / (float)F_total);
     return hipGetLastError();
 }
 

@@ -334,6 +334,7 @@ constexpr int kDppXor1 = 0xB1;   // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;   // quad_perm [2,3,0,1]
 constexpr int kDppRor4 = 0x124;  // row_ror:4
 constexpr int kDppRor8 = 0x128;  // row_ror:8
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane l <-> 7 - l inside each group of 8
 // a + b where b is the value of the lane 16 (32) lanes away: the swap of a register with itself
 // leaves {own row pair member, other row pair member} in the two results
 __device__ __forceinline__ float swapsum16(float v) {
@@ -406,6 +407,38 @@ struct Sq {
             v = swapmax32(v);
         }
         return v;
+    }
+    // sum over the columns of a row (every lane of the row gets it): the MP lanes of a row are consecutive
+    __device__ __forceinline__ R rowsum(R v) const {
+        v += dpp<kDppXor1>(v);
+        if constexpr (MP >= 4) v += dpp<kDppXor2>(v);
+        if constexpr (MP == 8) v += dpp<kDppHalfMirror>(v);   // quads are uniform: the mirror pairs quad 0 with quad 1
+        return v;
+    }
+    __device__ __forceinline__ Cx<R> rowsum(Cx<R> v) const { return {rowsum(v.re), rowsum(v.im)}; }
+    // value held by lane (r, c) of this lane's group
+    __device__ __forceinline__ Cx<R> at(Cx<R> v, int r, int c) const {
+        return {__shfl(v.re, r * MP + c, G), __shfl(v.im, r * MP + c, G)};
+    }
+    // inverse of a Hermitian positive definite matrix (identity outside M x M): in-place Gauss-Jordan, no pivot
+    // search (every pivot of an HPD elimination is a positive Schur complement)
+    __device__ __forceinline__ Cx<R> herm_inverse(Cx<R> A, int M) const {
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            if (k < M) {
+                const Cx<R> rk = colb(A, k);                 // A[k][j]
+                const Cx<R> ck = rowb(A, k);                 // A[i][k]
+                const Cx<R> d = cinv(rowb(rk, k));           // 1 / A[k][k]
+                const Cx<R> rkd = cmul(rk, d);
+                if (i == k)
+                    A = (j == k) ? d : rkd;
+                else if (j == k)
+                    A = Cx<R>{-(ck.re * d.re - ck.im * d.im), -(ck.re * d.im + ck.im * d.re)};
+                else
+                    cfms(A, ck, rkd);
+            }
+        }
+        return A;
     }
     // sum over all MP*MP lanes of the group
     __device__ __forceinline__ R allsum(R v) const {
@@ -590,6 +623,143 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
     if (fvalid && in) store_what<R>(a, ((size_t)f * M + j) * M + i, B.re, -B.im);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Structured form of the same update for 1 or 2 sources with background channels (K < M): the chain that
+// depends on W is a K x K solve and a few matrix-vector products instead of an M x M elimination with pivoting.
+//   W_hat^H = [[W^H], [J^H | -I]],  A = W_hat^H V,  A w = e_s   <=>   W_hat^H u = e_s,  u = V w:
+//     rows >= K :  u_bot = J^H u_top
+//     rows <  K :  Q u_top = e_s   with   Q = B_tt + B_tb B_bt   (B = W_hat^H in K | M-K blocks)      K x K
+//     w = V^-1 u                   V^-1 of the Hermitian positive definite V_s needs no pivoting and does not
+//                                  depend on W: all K inverses are formed before the chain starts
+//   w /= sqrt(w^H V w)  (overiva.py:185-186);  J from (W^H Cx)[:, :K]^-1 (W^H Cx)[:, K:] in closed form (:96-98).
+// Same lane layout as update_sq_kernel (lane (i, j) = element [i][j], one wavefront per bin at 8 channels).
+// Requires the -I block of W_hat (overiva.py:122-123), which every path of the library maintains.
+// ---------------------------------------------------------------------------------------------
+template <int MP, typename R, int MT, int KT>
+__global__ __launch_bounds__(kBlock) void update_bg_kernel(UpdateArgs a) {
+    static_assert(KT == 1 || KT == 2, "closed-form K x K solves");
+    constexpr int G = MP * MP;
+    constexpr int K = KT;
+    const int tid = threadIdx.x;
+    const Sq<MP, R> sq(tid % G);
+    const int i = sq.i, j = sq.j;
+    const int f_raw = blockIdx.x * (kBlock / G) + tid / G;
+    const bool fvalid = f_raw < a.F;
+    const int f = fvalid ? f_raw : a.F - 1;
+    const int M = MT ? MT : a.M;
+    const int NA = M * M;
+    const bool in = i < M && j < M;
+    const Cx<R> zero = {R(0), R(0)};
+    const Cx<R> eye = {R(i == j ? 1 : 0), R(0)};
+
+    Cx<R> B = eye;                        // B[i][j] = (W_hat^H)[i][j] = conj(W_hat[j][i]); identity outside M x M
+    if (in) {
+        R vr, vi;
+        load_what<R>(a, ((size_t)f * M + j) * M + i, vr, vi);
+        B = {vr, -vi};
+    }
+    if (a.wscale != nullptr && i < K) {  // overiva.py:163 / :167
+        const R sc = R(1) / R(a.wscale[i]);
+        B.re *= sc;
+        B.im *= sc;
+    }
+    int off = 0;
+    float sgn = 0.f;
+    if (in) herm_offsets(M, i, j, off, sgn);
+    Cx<R> C = zero;
+    if (in) {
+        const double* p = a.Cx + (size_t)f * NA + off;
+        C.re = R(p[0]);
+        if (sgn != 0.f) C.im = R(sgn * p[1]);
+    }
+    // V_s and V_s^-1 for all sources (off the chain); V_s[i][j] = (1/T) * fixed-order fp64 sum of the partials
+    const R invT = R(1) / R(a.T);
+    Cx<R> V[K], Vinv[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        V[s] = eye;
+        if (in) {
+            double sr = 0., si = 0.;
+            const size_t base = ((size_t)f * K + s) * NA + off;
+            const size_t stride = (size_t)a.F * K * NA;
+            const bool has_im = sgn != 0.f;
+#pragma unroll 4
+            for (int sp = 0; sp < a.nsplit; ++sp) {
+                sr += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride);
+                if (has_im) si += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride + 1);
+            }
+            V[s] = {R(sr) * invT, R(si) * R(sgn) * invT};
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < K; ++s) Vinv[s] = sq.herm_inverse(V[s], M);
+
+    Cx<R> Tm = sq.matmul(B, C, M);        // rows < K: W^H Cx (rows >= K unused)
+    Cx<R> Bt = sq.transp(B);              // lane (i, j): B[j][i]
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        // Q = B_tt + B_tb B_bt on lanes i, j < K
+        Cx<R> Q = B;
+#pragma unroll
+        for (int m = K; m < MP; ++m) {
+            if (m < M) cfma(Q, sq.rowb(B, m), sq.colb(B, m));
+        }
+        // u_top = Q^-1 e_s
+        Cx<R> u0, u1 = zero;
+        if constexpr (K == 1) {
+            u0 = cinv(sq.at(Q, 0, 0));
+        } else {
+            const Cx<R> q00 = sq.at(Q, 0, 0), q01 = sq.at(Q, 0, 1), q10 = sq.at(Q, 1, 0), q11 = sq.at(Q, 1, 1);
+            Cx<R> det = cmul(q00, q11);
+            cfms(det, q01, q10);
+            const Cx<R> idet = cinv(det);
+            u0 = s == 0 ? cmul(q11, idet) : cmul(Cx<R>{-q01.re, -q01.im}, idet);
+            u1 = s == 0 ? cmul(Cx<R>{-q10.re, -q10.im}, idet) : cmul(q00, idet);
+        }
+        // u, one entry per column: u_j = u_top[j] (j < K) | sum_m B[j][m] u_top[m] (K <= j < M)
+        Cx<R> ub = cmul(sq.colb(Bt, 0), u0);
+        if constexpr (K == 2) cfma(ub, sq.colb(Bt, 1), u1);
+        Cx<R> uj = j == 0 ? u0 : ((K == 2 && j == 1) ? u1 : ub);
+        if (j >= M) uj = zero;
+        // w = V^-1 u (one entry per row), then its copy per column
+        Cx<R> wi = sq.rowsum(cmul(Vinv[s], uj));
+        Cx<R> wj = sq.transp(wi);
+        // d = w^H V w, overiva.py:185
+        const Cx<R> vw = sq.rowsum(cmul(V[s], wj));
+        const R d = sq.allsum(j == 0 && i < M ? wi.re * vw.re + wi.im * vw.im : R(0));
+        const R sc = fast_rsqrt(d);
+        wi.re *= sc;
+        wi.im *= sc;
+        wj.re *= sc;
+        wj.im *= sc;
+        if (i == s && j < M) B = {wj.re, -wj.im};
+        // J from the orthogonality constraint, overiva.py:189-190 -> :96-98; row s of W^H Cx = sum_i conj(w_i) Cx[i][:]
+        Cx<R> t = cmul(Cx<R>{wi.re, -wi.im}, C);
+        t.re = sq.colsum(t.re);
+        t.im = sq.colsum(t.im);
+        if (i == s) Tm = t;
+        Cx<R> Jn;                          // lanes i < K, j >= K: J[i][j - K]
+        if constexpr (K == 1) {
+            Jn = cmul(sq.colb(Tm, 0), cinv(sq.at(Tm, 0, 0)));
+        } else {
+            const Cx<R> t00 = sq.at(Tm, 0, 0), t01 = sq.at(Tm, 0, 1), t10 = sq.at(Tm, 1, 0), t11 = sq.at(Tm, 1, 1);
+            const Cx<R> r0 = sq.colb(Tm, 0), r1 = sq.colb(Tm, 1);        // Tm[0][j], Tm[1][j]
+            Cx<R> det = cmul(t00, t11);
+            cfms(det, t01, t10);
+            const Cx<R> idet = cinv(det);
+            Cx<R> n0 = cmul(t11, r0), n1 = cmul(t00, r1);
+            cfms(n0, t01, r1);
+            cfms(n1, t10, r0);
+            Jn = cmul(i == 0 ? n0 : n1, idet);
+        }
+        // W_hat[m][i] = J[m][i - K]  ->  (W_hat^H)[i][m] = conj, for K <= i < M, m = j < K
+        const Cx<R> Jt = sq.transp(Jn);
+        if (j < K && i >= K && i < M) B = {Jt.re, -Jt.im};
+        Bt = sq.transp(B);
+    }
+    if (fvalid && in) store_what<R>(a, ((size_t)f * M + j) * M + i, B.re, -B.im);
+}
+
 template <int MP, int MT, int KT>
 hipError_t launch_sq_one(hipStream_t s, const UpdateArgs& a) {
     const int bins_per_block = kBlock / (MP * MP);
@@ -603,8 +773,25 @@ hipError_t launch_sq_one(hipStream_t s, const UpdateArgs& a) {
 
 // specialised instantiations for the common shapes (full power-of-two channel count with 2 sources or
 // determined), generic otherwise
+template <int MP, int MT, int KT>
+hipError_t launch_bg_one(hipStream_t s, const UpdateArgs& a) {
+    const int bins_per_block = kBlock / (MP * MP);
+    dim3 grid((a.F + bins_per_block - 1) / bins_per_block);
+    if (a.use_double)
+        hipLaunchKernelGGL((update_bg_kernel<MP, double, MT, KT>), grid, dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL((update_bg_kernel<MP, float, MT, KT>), grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int MP>
 hipError_t launch_sq(hipStream_t s, const UpdateArgs& a) {
+    // 1 or 2 sources with background channels: the structured chain (the J initialisation of the prologue keeps
+    // the generic kernel)
+    if (!a.init_only && a.K < a.M && MP >= 4) {
+        if (a.K == 2) return a.M == MP ? launch_bg_one<MP, MP, 2>(s, a) : launch_bg_one<MP, 0, 2>(s, a);
+        if (a.K == 1) return a.M == MP ? launch_bg_one<MP, MP, 1>(s, a) : launch_bg_one<MP, 0, 1>(s, a);
+    }
     if (a.M == MP) {
         if (a.K == 2 && MP >= 2) return launch_sq_one<MP, MP, 2>(s, a);
         if (a.K == MP) return launch_sq_one<MP, MP, MP>(s, a);

@@ -21,23 +21,14 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
     return s;
 }
 
-// gamma_k = mean_t R[t,k]  (reference overiva.py:158), computed by a whole workgroup in a fixed order so
-// that every workgroup of every kernel obtains the same bits.  R is (T, K), a few KB, L2 resident.
-// Loads are issued 16 at a time so the cost is a couple of memory round trips, not T/256 of them.
-__device__ __forceinline__ double block_gamma(const float* __restrict__ R, int T, int K, int k, double* scratch) {
-    constexpr int kBatch = 16;
+// gamma_k = mean_t R[t,k]  (reference overiva.py:158) from the per-block partial sums the activation kernel left
+// behind R (rsum_offset_floats): a fixed-order sum of T/256 float64 values at wave-uniform addresses (scalar
+// loads), so every lane of every kernel obtains the same bits for the price of a few instructions.
+__device__ __forceinline__ double gamma_of(const float* __restrict__ R, int T, int K, int k) {
+    const double* S = reinterpret_cast<const double*>(R + rsum_offset_floats(T, K));
+    const int nblk = rsum_blocks(T);
     double s = 0.;
-    for (int t0 = threadIdx.x; t0 < T; t0 += kBlock * kBatch) {
-        float v[kBatch];
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            const int t = t0 + u * kBlock;
-            v[u] = R[(size_t)(t < T ? t : T - 1) * K + k];
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) s += (t0 + u * kBlock < T) ? (double)v[u] : 0.;
-    }
-    s = block_sum(s, scratch);
+    for (int b = 0; b < nblk; ++b) s += S[(size_t)b * K + k];
     return s / (double)T;
 }
 

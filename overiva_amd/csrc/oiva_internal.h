@@ -23,6 +23,16 @@ __host__ __device__ inline int herm_pair_index(int M, int c, int d) {  // c < d
     return M + 2 * (c * M - (c * (c + 1)) / 2 + (d - c - 1));
 }
 
+// Layout of the activation buffer R: (T, K) float32 activations r, kPhasesPerWave zeroed pad rows (kernels read
+// whole groups of 4 frames), then -- 8-byte aligned -- one float64 partial sum of r per (block of kBlock frames,
+// source), written by the activation kernel, from which every consumer derives gamma_k = mean_t r[t,k]
+// (overiva.py:158) in the same fixed order.
+__host__ __device__ inline size_t rsum_offset_floats(int T, int K) { return (((size_t)T + kPhasesPerWave) * K + 1) & ~(size_t)1; }
+__host__ __device__ inline int rsum_blocks(int T) { return (T + kBlock - 1) / kBlock; }
+__host__ __device__ inline size_t r_buffer_bytes(int T, int K) {
+    return rsum_offset_floats(T, K) * sizeof(float) + (size_t)rsum_blocks(T) * K * sizeof(double);
+}
+
 struct CovGeom {
     int nsplit;   // frame splits (grid.y)
     int tc;       // frames per split (multiple of 16)

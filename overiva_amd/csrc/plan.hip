@@ -377,8 +377,8 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     alloc((void**)&p->Ppart, (size_t)p->pw.nb * nTK * sizeof(float));
     p->ppart_alloc = p->pw.nb;
     alloc((void**)&p->Plocal, std::max(nTK, (size_t)T * 16) * sizeof(float));   // also the (T, 16) weights scratch
-    alloc((void**)&p->R, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));   // zeroed tail rows: see cov_dma_kernel
-    if (e == hipSuccess) e = hipMemset(p->R, 0, (nTK + (size_t)kPhasesPerWave * K) * sizeof(float));
+    alloc((void**)&p->R, r_buffer_bytes(T, K));   // activations, zeroed pad rows, per-block sums (rsum_offset_floats)
+    if (e == hipSuccess) e = hipMemset(p->R, 0, r_buffer_bytes(T, K));
     alloc((void**)&p->wscale, (size_t)K * sizeof(float));
     alloc((void**)&p->Spart, (size_t)p->stg.nsplit * F * K * 3 * sizeof(float));
     alloc((void**)&p->scratch_c, (size_t)K * nFMM * sizeof(double2));
