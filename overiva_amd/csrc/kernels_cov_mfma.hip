@@ -50,8 +50,6 @@ __global__ __launch_bounds__(64, 2) void cov_mfma16_kernel(const float2* __restr
     const int NA = M * M;
     const bool cvalid = ch < M;
     const float xmask = cvalid ? 1.f : 0.f;
-    // arithmetic select of the lane's frame among the group's four (the weights are wave-uniform scalars)
-    const float m0 = kf == 0 ? 1.f : 0.f, m1 = kf == 1 ? 1.f : 0.f, m2 = kf == 2 ? 1.f : 0.f, m3 = kf == 3 ? 1.f : 0.f;
     acc_t are[KW], air[KW];
 #pragma unroll
     for (int kk = 0; kk < KW; ++kk)
@@ -61,36 +59,59 @@ __global__ __launch_bounds__(64, 2) void cov_mfma16_kernel(const float2* __restr
     const size_t frame_stride = (size_t)F * M;                         // complex samples per frame
     const float2* pcol = X + (size_t)f * M + (cvalid ? ch : 0);
     const int ngroups = (t_end - t_begin + 3) >> 2;
+    // x of group g: this lane's channel at frame t_begin + 4g + kf (frames past the split: clamped, masked below)
     auto fetch = [&](int g) {
         const int t = t_begin + 4 * g + kf;
         return pcol[(size_t)(t < t_end ? t : T - 1) * frame_stride];
     };
-    // kDepth groups of x are in flight per wave (8 bytes per lane and group): with few sources the MFMA work
-    // per group is short and a single outstanding load leaves the wave waiting on HBM
-    constexpr int kDepth = 4;
+    // the KW weights of the lane's own frame: one row of the (T, Kp) table, as KW/4 (or fewer) 16-byte loads that
+    // the 16 lanes of a frame share.  (Selecting them from wave-uniform scalar loads of all four frames costs
+    // 4 FMAs per source on the VALU, next to 3 MFMAs per source: measured 1.95 -> see DESIGN.md.)
+    constexpr int WV = (KW + 3) / 4;
+    auto fetch_w = [&](int g, float4 (&w)[WV]) {
+        const int t = min(t_begin + 4 * g + kf, T - 1);
+        const float4* row = reinterpret_cast<const float4*>(Wt + (size_t)t * Kp + k0);
+#pragma unroll
+        for (int v = 0; v < WV; ++v) w[v] = row[v];
+    };
+    // kDepth groups of x and kWDepth groups of weights are in flight per wave
+    constexpr int kDepth = 4, kWDepth = 2;
     float2 xq[kDepth];
+    float4 wq[kWDepth][WV];
 #pragma unroll
     for (int u = 0; u < kDepth; ++u) xq[u] = fetch(u < ngroups ? u : ngroups - 1);
+    if constexpr (!UNIT) {
+#pragma unroll
+        for (int u = 0; u < kWDepth; ++u) fetch_w(u < ngroups ? u : ngroups - 1, wq[u]);
+    }
     for (int g0 = 0; g0 < ngroups; g0 += kDepth) {
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
             const int g = g0 + u;
             const float2 x = xq[u];
             xq[u] = fetch(g + kDepth < ngroups ? g + kDepth : ngroups - 1);
+            float wl[4 * WV];
+            if constexpr (!UNIT) {
+#pragma unroll
+                for (int v = 0; v < WV; ++v) {
+                    wl[4 * v] = wq[u % kWDepth][v].x;
+                    wl[4 * v + 1] = wq[u % kWDepth][v].y;
+                    wl[4 * v + 2] = wq[u % kWDepth][v].z;
+                    wl[4 * v + 3] = wq[u % kWDepth][v].w;
+                }
+                fetch_w(g + kWDepth < ngroups ? g + kWDepth : ngroups - 1, wq[u % kWDepth]);
+            }
             if (g < ngroups) {                                         // uniform
                 const int t0 = t_begin + 4 * g;
                 const float live = (t0 + kf < t_end) ? xmask : 0.f;
                 const REAL xr = (REAL)(x.x * live), xi = (REAL)(x.y * live);
-                // Wt is (T, Kp) with zero padding columns; rows past T-1 in the last group are clamped (uniform)
-                const float* w0 = Wt + (size_t)min(t0, T - 1) * Kp + k0;
-                const float* w1 = Wt + (size_t)min(t0 + 1, T - 1) * Kp + k0;
-                const float* w2 = Wt + (size_t)min(t0 + 2, T - 1) * Kp + k0;
-                const float* w3 = Wt + (size_t)min(t0 + 3, T - 1) * Kp + k0;
 #pragma unroll
                 for (int kk = 0; kk < KW; ++kk) {
-                    float w = 1.f;
-                    if constexpr (!UNIT) w = m0 * w0[kk] + m1 * w1[kk] + m2 * w2[kk] + m3 * w3[kk];
-                    const REAL ar = xr * (REAL)w, ai = xi * (REAL)w;
+                    REAL ar = xr, ai = xi;
+                    if constexpr (!UNIT) {
+                        ar = xr * (REAL)wl[kk];
+                        ai = xi * (REAL)wl[kk];
+                    }
                     are[kk] = Mfma<REAL>::run(ar, xr, are[kk]);
                     are[kk] = Mfma<REAL>::run(ai, xi, are[kk]);
                     air[kk] = Mfma<REAL>::run(ai, xr, air[kk]);

@@ -11,8 +11,9 @@
 namespace oiva {
 namespace {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kBinsPerBatch = kBinsPerWave * kWaves;   // 64: same batches (and Ppart layout) as power_kernel
+
+constexpr int kFrameTiles = 4;       // 16-frame tiles per wave: the W operands of a bin are loaded once for 64 frames
 
 __global__ __launch_bounds__(kBlock) void power_mfma_kernel(const float2* __restrict__ X, const float2* __restrict__ What,
                                                             float* __restrict__ Ppart, int T, int F, int M, int K) {
@@ -20,60 +21,85 @@ __global__ __launch_bounds__(kBlock) void power_mfma_kernel(const float2* __rest
     const int wave = threadIdx.x >> 6;
     const int j = lane & 15;             // A: source (row) | B: frame (column)
     const int q = lane >> 4;             // channel within the chunk of 4 (contraction index)
-    const int t = (blockIdx.y * kWaves + wave) * 16 + j;
-    const int tcl = t < T ? t : T - 1;
-    const float tmask = t < T ? 1.f : 0.f;
+    const int t0 = (blockIdx.y * kWaves + wave) * 16 * kFrameTiles + j;
     const int f0 = blockIdx.x * kBinsPerBatch;
     const int nbins = min(kBinsPerBatch, F - f0);
     const int nchunks = (M + 3) >> 2;
 
-    float P[4] = {0.f, 0.f, 0.f, 0.f};   // sources 4q..4q+3 at frame j
+    float P[kFrameTiles][4];             // sources 4q..4q+3 at frame t0 + 16 * tile
+    const float2* px[kFrameTiles];
+    float tmask[kFrameTiles];
     const size_t frame_stride = (size_t)F * M;
-    const float2* px = X + (size_t)tcl * frame_stride + (size_t)f0 * M;   // + b*M + m
-    const float2* pw = What + (size_t)f0 * M * M;                         // + (b*M + m)*M + k
+#pragma unroll
+    for (int tl = 0; tl < kFrameTiles; ++tl) {
+        const int t = t0 + 16 * tl;
+        tmask[tl] = t < T ? 1.f : 0.f;
+        px[tl] = X + (size_t)(t < T ? t : T - 1) * frame_stride + (size_t)f0 * M;   // + b*M + m
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[tl][r] = 0.f;
+    }
+    const float2* pw = What + (size_t)f0 * M * M;                                   // + (b*M + m)*M + k
 
     // operands of one bin: chunk c holds channel m = 4c + q; zero outside M x K
-    auto fetch = [&](int b, float2 (&w)[4], float2 (&x)[4]) {
+    auto fetch_w = [&](int b, float2 (&w)[4]) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int m = 4 * c + q;
-            const bool mv = m < M;
-            const int mc = mv ? m : 0;
-            const float2 wv = pw[((size_t)b * M + mc) * M + (j < K ? j : 0)];
-            const float2 xv = px[(size_t)b * M + mc];
-            const float wm = (mv && j < K) ? 1.f : 0.f, xm = mv ? tmask : 0.f;
-            w[c] = make_float2(wv.x * wm, wv.y * wm);
-            x[c] = make_float2(xv.x * xm, xv.y * xm);
+            const bool ok = m < M && j < K;
+            const float2 wv = pw[((size_t)b * M + (m < M ? m : 0)) * M + (j < K ? j : 0)];
+            w[c] = make_float2(ok ? wv.x : 0.f, ok ? wv.y : 0.f);
         }
     };
-    float2 w[4], x[4], wn[4], xn[4];
-    fetch(0, w, x);
-    for (int b = 0; b < nbins; ++b) {
-        fetch(b + 1 < nbins ? b + 1 : b, wn, xn);     // next bin's operands are in flight during the MFMAs
-        f32x4 yr = {0.f, 0.f, 0.f, 0.f}, yi = {0.f, 0.f, 0.f, 0.f};
+    auto fetch_x = [&](int b, float2 (&x)[kFrameTiles][4]) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c < nchunks) {
-                yr = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].x, x[c].x, yr, 0, 0, 0);
-                yi = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].x, x[c].y, yi, 0, 0, 0);
-                yr = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].y, x[c].y, yr, 0, 0, 0);
-                yi = __builtin_amdgcn_mfma_f32_16x16x4f32(-w[c].y, x[c].x, yi, 0, 0, 0);
+        for (int tl = 0; tl < kFrameTiles; ++tl)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int m = 4 * c + q;
+                x[tl][c] = px[tl][(size_t)b * M + (m < M ? m : 0)];
             }
+    };
+    float2 w[4], wn[4], x[kFrameTiles][4], xn[kFrameTiles][4];
+    fetch_w(0, w);
+    fetch_x(0, x);
+    for (int b = 0; b < nbins; ++b) {
+        const int bn = b + 1 < nbins ? b + 1 : b;
+        fetch_w(bn, wn);                 // next bin's operands are in flight during the MFMAs
+        fetch_x(bn, xn);
+#pragma unroll
+        for (int tl = 0; tl < kFrameTiles; ++tl) {
+            f32x4 yr = {0.f, 0.f, 0.f, 0.f}, yi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < nchunks) {
+                    const float xm = (4 * c + q < M) ? tmask[tl] : 0.f;
+                    const float xr = x[tl][c].x * xm, xi = x[tl][c].y * xm;
+                    yr = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].x, xr, yr, 0, 0, 0);
+                    yi = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].x, xi, yi, 0, 0, 0);
+                    yr = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].y, xi, yr, 0, 0, 0);
+                    yi = __builtin_amdgcn_mfma_f32_16x16x4f32(-w[c].y, xr, yi, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[tl][r] = fmaf(yr[r], yr[r], fmaf(yi[r], yi[r], P[tl][r]));
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) P[r] = fmaf(yr[r], yr[r], fmaf(yi[r], yi[r], P[r]));
+        for (int c = 0; c < 4; ++c) w[c] = wn[c];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            w[c] = wn[c];
-            x[c] = xn[c];
-        }
+        for (int tl = 0; tl < kFrameTiles; ++tl)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[tl][c] = xn[tl][c];
     }
     // D layout: lane l, register r = [source 4*(l>>4) + r][frame l&15]
-    if (t < T) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = 4 * q + r;
-            if (k < K) Ppart[((size_t)blockIdx.x * T + t) * K + k] = P[r];
+    for (int tl = 0; tl < kFrameTiles; ++tl) {
+        const int t = t0 + 16 * tl;
+        if (t < T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * q + r;
+                if (k < K) Ppart[((size_t)blockIdx.x * T + t) * K + k] = P[tl][r];
+            }
         }
     }
 }
@@ -81,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void power_mfma_kernel(const float2* __rest
 }  // namespace
 
 hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K) {
-    dim3 grid((F + kBinsPerBatch - 1) / kBinsPerBatch, (T + 16 * kWaves - 1) / (16 * kWaves));
+    dim3 grid((F + kBinsPerBatch - 1) / kBinsPerBatch, (T + 16 * kWaves * kFrameTiles - 1) / (16 * kWaves * kFrameTiles));
     power_mfma_kernel<<<grid, dim3(kBlock), 0, s>>>(X, What, Ppart, T, F, M, K);
     return hipGetLastError();
 }

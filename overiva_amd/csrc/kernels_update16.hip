@@ -159,25 +159,33 @@ __global__ __launch_bounds__(kBlock) void update_lds16_kernel(UpdateArgs a) {
 
     const int nsrc = a.init_only ? 0 : K;
     const R invT = R(1) / R(a.T);
+    // V_s[i][j]: fixed-order fp64 sum of the frame-split partials; the loads of source s+1 are issued before
+    // source s is solved
+    auto load_v = [&](int src) {
+        C2<R> V = zero;
+        if (in) {
+            double sr = 0., si = 0.;
+            const size_t base = ((size_t)f * K + src) * NA + off;
+            const size_t stride = (size_t)a.F * K * NA;
+#pragma unroll 4
+            for (int sp = 0; sp < a.nsplit; ++sp) {
+                sr += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride);
+                if (sgn != 0.f) si += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride + 1);
+            }
+            V.re = R(sr) * invT;
+            V.im = R(si) * R(sgn) * invT;
+        }
+        return V;
+    };
+    C2<R> Vnext = zero;
+    if (nsrc > 0) Vnext = load_v(0);
     for (int src = 0; src <= nsrc; ++src) {
         const bool solve = src < nsrc;
         if (!solve && !a.init_only) break;
         C2<R> wi = zero, wj = zero;
         if (solve) {
-            // V_s[i][j]: fixed-order fp64 sum of the frame-split partials
-            C2<R> V = zero;
-            if (in) {
-                double sr = 0., si = 0.;
-                const size_t base = ((size_t)f * K + src) * NA + off;
-                const size_t stride = (size_t)a.F * K * NA;
-#pragma unroll 4
-                for (int sp = 0; sp < a.nsplit; ++sp) {
-                    sr += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride);
-                    if (sgn != 0.f) si += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride + 1);
-                }
-                V.re = R(sr) * invT;
-                V.im = R(si) * R(sgn) * invT;
-            }
+            const C2<R> V = Vnext;
+            if (src + 1 < nsrc) Vnext = load_v(src + 1);
             C2<R> A = matmul(s, B, V, i, j, M);   // W_hat^H V
             if (!in) A = eye;
             C2<R> rhs = {R(i == src ? 1 : 0), R(0)};
