@@ -204,12 +204,9 @@ __global__ __launch_bounds__(kBlock) void update_kernel(UpdateArgs a) {
                     int off;
                     float sgn;
                     herm_offsets(M, i, j, off, sgn);
-                    double sr = 0., si = 0.;
-                    for (int sp = 0; sp < a.nsplit; ++sp) {
-                        const size_t idx = (((size_t)sp * a.F + f) * K + s) * NA + off;
-                        sr += load_vpart(a.Vpart, a.vpart_f64, idx);
-                        if (sgn != 0.f) si += load_vpart(a.Vpart, a.vpart_f64, idx + 1);
-                    }
+                    double sr, si;
+                    sum_vpart(a.Vpart, a.vpart_f64, ((size_t)f * K + s) * NA + off, (size_t)a.F * K * NA, a.nsplit, sgn != 0.f,
+                              sr, si);
                     Vr[j].re = R(sr) * invT;
                     Vr[j].im = R(si) * R(sgn) * invT;
                 }
@@ -548,15 +545,8 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
     auto load_v = [&](int s) {
         Cx<R> V = zero;
         if (in) {
-            double sr = 0., si = 0.;
-            const size_t base = ((size_t)f * K + s) * NA + off;
-            const size_t stride = (size_t)a.F * K * NA;
-            const bool has_im = sgn != 0.f;
-#pragma unroll 4
-            for (int sp = 0; sp < a.nsplit; ++sp) {
-                sr += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride);
-                if (has_im) si += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride + 1);
-            }
+            double sr, si;
+            sum_vpart(a.Vpart, a.vpart_f64, ((size_t)f * K + s) * NA + off, (size_t)a.F * K * NA, a.nsplit, sgn != 0.f, sr, si);
             V.re = R(sr) * invT;
             V.im = R(si) * R(sgn) * invT;
         }
@@ -679,15 +669,8 @@ __global__ __launch_bounds__(kBlock) void update_bg_kernel(UpdateArgs a) {
     for (int s = 0; s < K; ++s) {
         V[s] = eye;
         if (in) {
-            double sr = 0., si = 0.;
-            const size_t base = ((size_t)f * K + s) * NA + off;
-            const size_t stride = (size_t)a.F * K * NA;
-            const bool has_im = sgn != 0.f;
-#pragma unroll 4
-            for (int sp = 0; sp < a.nsplit; ++sp) {
-                sr += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride);
-                if (has_im) si += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride + 1);
-            }
+            double sr, si;
+            sum_vpart(a.Vpart, a.vpart_f64, ((size_t)f * K + s) * NA + off, (size_t)a.F * K * NA, a.nsplit, sgn != 0.f, sr, si);
             V[s] = {R(sr) * invT, R(si) * R(sgn) * invT};
         }
     }

@@ -164,14 +164,8 @@ __global__ __launch_bounds__(kBlock) void update_lds16_kernel(UpdateArgs a) {
     auto load_v = [&](int src) {
         C2<R> V = zero;
         if (in) {
-            double sr = 0., si = 0.;
-            const size_t base = ((size_t)f * K + src) * NA + off;
-            const size_t stride = (size_t)a.F * K * NA;
-#pragma unroll 4
-            for (int sp = 0; sp < a.nsplit; ++sp) {
-                sr += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride);
-                if (sgn != 0.f) si += load_vpart(a.Vpart, a.vpart_f64, base + sp * stride + 1);
-            }
+            double sr, si;
+            sum_vpart(a.Vpart, a.vpart_f64, ((size_t)f * K + src) * NA + off, (size_t)a.F * K * NA, a.nsplit, sgn != 0.f, sr, si);
             V.re = R(sr) * invT;
             V.im = R(si) * R(sgn) * invT;
         }

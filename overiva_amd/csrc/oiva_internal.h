@@ -124,6 +124,40 @@ __device__ __forceinline__ void store_what(const UpdateArgs& a, size_t idx, R re
 __device__ __forceinline__ double load_vpart(const void* base, int f64, size_t idx) {
     return f64 ? static_cast<const double*>(base)[idx] : (double)static_cast<const float*>(base)[idx];
 }
+// fixed-order float64 sum of the nsplit frame-split partials of one packed element and of its neighbour idx + 1
+// (the imaginary part of an off-diagonal entry; a valid address for every element of a packed matrix with M > 1,
+// discarded by the caller where it means nothing).  Branch-free: the loads of 16 splits are issued together
+// (splits past nsplit re-read the last one and are masked), so a sum costs one memory round trip per 16 splits.
+template <typename P>
+__device__ __forceinline__ void sum_vpart_t(const P* __restrict__ base, size_t idx, size_t stride, int nsplit, double& sr,
+                                            double& si) {
+    constexpr int kBatch = 16;
+    sr = 0.;
+    si = 0.;
+    for (int s0 = 0; s0 < nsplit; s0 += kBatch) {
+        P vr[kBatch], vi[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int sp = s0 + u < nsplit ? s0 + u : nsplit - 1;
+            vr[u] = base[idx + (size_t)sp * stride];
+            vi[u] = base[idx + (size_t)sp * stride + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const double m = s0 + u < nsplit ? 1. : 0.;
+            sr += m * (double)vr[u];
+            si += m * (double)vi[u];
+        }
+    }
+}
+__device__ __forceinline__ void sum_vpart(const void* base, int f64, size_t idx, size_t stride, int nsplit, bool pair,
+                                          double& sr, double& si) {
+    if (f64)          // uniform
+        sum_vpart_t(static_cast<const double*>(base), idx, stride, nsplit, sr, si);
+    else
+        sum_vpart_t(static_cast<const float*>(base), idx, stride, nsplit, sr, si);
+    if (!pair) si = 0.;
+}
 hipError_t launch_update(hipStream_t s, const UpdateArgs& a);
 hipError_t launch_update_lds16(hipStream_t s, const UpdateArgs& a);   // 9..16 channels, one workgroup per bin
 

@@ -119,12 +119,12 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         // fixed cost (gamma prologue, ring fill, epilogue), so fewer, longer workgroups win as long as the chip
         // is full, and 1.5 rounds run as long as 2
         nsplit = pick_splits(p->n_cu * bpc, g.nbg * nz, p->T, 128);
-        // the update kernel adds the nsplit partials of every matrix element one dependent round of loads
-        // per 4 splits: beyond 16 splits that costs more there than the fuller grid saves here (measured
-        // on a 256-bin shard: update 19.4 -> 15.6 us, covariance unchanged)
-        // ... unless 16 splits would leave most of the chip idle (few bins, very long frame axis): then the
+        // the update kernel adds the nsplit partials of every matrix element in one round of loads per 16 splits
+        // (sum_vpart); more than 32 splits cost more there than the fuller grid saves here (measured on a
+        // 256-bin shard: 16 splits 25.2 + 8.0 us, 28 splits 21.4 + 9.2 us, 42 splits 25.5 + 10.3 us)
+        // ... unless 32 splits would leave most of the chip idle (few bins, very long frame axis): then the
         // streaming pass dominates and up to 64 splits are allowed
-        const int cap = (g.nbg * nz * 16 >= p->n_cu) ? 16 : 64;
+        const int cap = (g.nbg * nz * 32 >= p->n_cu) ? 32 : 64;
         nsplit = std::min(nsplit, cap);
     }
     if (gram) nsplit = std::max(nsplit, ceil_div(p->T, cov_gram_max_frames() - 4));   // the kernel's weight table
@@ -182,7 +182,7 @@ int ensure_vpart(oiva_plan* p) {
     if (p->cov.nsplit > p->vpart_splits_alloc) {
         if (p->Vpart) HIP_TRY(hipFree(p->Vpart));
         p->Vpart = nullptr;
-        HIP_TRY(hipMalloc(&p->Vpart, vpart_floats(p, p->cov.nsplit) * sizeof(double)));   // either element type
+        HIP_TRY(hipMalloc(&p->Vpart, (vpart_floats(p, p->cov.nsplit) + 2) * sizeof(double)));   // either element type; sum_vpart reads idx + 1
         p->vpart_splits_alloc = p->cov.nsplit;
     }
     return OIVA_OK;
