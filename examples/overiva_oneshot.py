@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """
 One-shot separation demo with the reference's command line (overiva_oneshot.py:72-116), on a
-synthetic convolutive-style mixture instead of a simulated room (the reference needs pyroomacoustics,
+synthetic convolutive mixture instead of a simulated room (the reference needs pyroomacoustics,
 mir_eval and a dataset download for that part, which are outside this repository's scope):
 
     python examples/overiva_oneshot.py -a overiva -m 4 -s 2 -n 20 [-d laplace|gauss] [-i eye|eig] [--no_cb]
+
+The flow is the reference's (overiva_oneshot.py:293-379): time-domain microphone signals -> STFT (frame 4096, hop
+2048, Hann; on the GPU, overiva_amd.stft) -> separation -> inverse STFT of the separated channels; `--domain stft`
+skips the transforms and draws the mixture directly in the STFT domain.
 
 What it keeps from the reference driver: the algorithm choices and their dispatch
 (overiva_oneshot.py:301-330: 'auxiva' = all channels, 'auxiva_pca' = PCA + determined, 'overiva' = n_src
@@ -40,6 +44,27 @@ def synthetic_scene(n_mics, n_targets, n_frames, n_freq, seed, sinr_db=10.0):
     return (mix + noise).astype(np.complex128), images
 
 
+def synthetic_audio_scene(n_mics, n_targets, n_frames, framesize, seed, sinr_db=10.0, taps=48):
+    """time-domain scene: n_targets sources with slowly varying activity, each reaching every microphone through
+    its own short random filter (convolutive mixture), plus white noise.  Returns the microphone signals
+    (n_samples, n_mics) and the source images at the microphones (n_samples, n_mics, n_targets)."""
+    rng = np.random.default_rng(seed)
+    hop = framesize // 2
+    n = n_frames * hop
+    seg = hop // 2
+    env = np.repeat(rng.gamma(0.3, 1.0, (n // seg + 1, n_targets)), seg, axis=0)[:n]
+    src = env * rng.standard_normal((n, n_targets))
+    h = rng.standard_normal((n_mics, n_targets, taps)) * np.exp(-np.arange(taps) / 8.0)
+    images = np.empty((n, n_mics, n_targets))
+    for m in range(n_mics):
+        for k in range(n_targets):
+            images[:, m, k] = np.convolve(src[:, k], h[m, k])[:n]
+    mix = images.sum(axis=-1)
+    noise = rng.standard_normal(mix.shape)
+    noise *= np.sqrt(np.mean(mix ** 2) / np.mean(noise ** 2) / 10 ** (sinr_db / 10))
+    return mix + noise, images
+
+
 def sir_db(W, images):
     """mean over sources of best-permutation SIR of y_k = w_k^H x, from the known source images"""
     Y = np.einsum("fmk,tfmj->tfkj", np.conj(W), images)            # output k due to source j
@@ -64,6 +89,8 @@ def parse_args(argv=None):
     ap.add_argument("-s", "--srcs", type=int, default=2, help="Number of sources")
     ap.add_argument("-n", "--n_iter", type=int, default=51, help="Number of iterations")
     ap.add_argument("--frames", type=int, default=160, help="STFT frames of the synthetic scene")
+    ap.add_argument("--domain", choices=["audio", "stft"], default="audio",
+                    help="audio: time-domain scene, STFT and inverse STFT on the GPU (the reference's flow); stft: scene drawn in the STFT domain")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args(argv)
     assert args.srcs <= args.mics, "More sources than microphones is not supported"      # overiva_oneshot.py:118
@@ -99,11 +126,23 @@ def run(argv=None, verbose=True):
     args = parse_args(argv)
     from overiva_amd import auxiva_pca, overiva
 
+    from overiva_amd import stft as transform
+
     framesize = 4096                                  # overiva_oneshot.py:156
     n_freq = framesize // 2 + 1
-    X_mics, images = synthetic_scene(args.mics, args.srcs, args.frames, n_freq, args.seed)
+    mics_signals = None
+    if args.domain == "audio":
+        win_a = transform.hann(framesize)             # overiva_oneshot.py:157-158
+        win_s = transform.compute_synthesis_window(win_a, framesize // 2)
+        mics_signals, images_t = synthetic_audio_scene(args.mics, args.srcs, args.frames, framesize, args.seed)
+        # overiva_oneshot.py:293-296: analysis of all microphones, complex128, (n_frames, n_freq, n_mics)
+        X_mics = transform.analysis(mics_signals, framesize, framesize // 2, win=win_a).astype(np.complex128)
+        images = np.stack([transform.analysis(images_t[:, :, k], framesize, framesize // 2, win=win_a)
+                           for k in range(args.srcs)], axis=-1).astype(np.complex128)
+    else:
+        X_mics, images = synthetic_scene(args.mics, args.srcs, args.frames, n_freq, args.seed)
     if verbose:
-        print(f"scene: {args.frames} frames x {n_freq} bins x {args.mics} mics, {args.srcs} targets, dtype {X_mics.dtype}")
+        print(f"scene ({args.domain}): {X_mics.shape[0]} frames x {n_freq} bins x {args.mics} mics, {args.srcs} targets, dtype {X_mics.dtype}")
     trace = []
 
     def convergence_callback(Y):                      # overiva_oneshot.py:263-284 (metric instead of bss_eval)
@@ -113,6 +152,9 @@ def run(argv=None, verbose=True):
     t_begin = time.perf_counter()                     # overiva_oneshot.py:298
     Y = separate(args, X_mics, overiva, auxiva_pca, cb)
     t_end = time.perf_counter()
+    y = None
+    if args.domain == "audio":                        # overiva_oneshot.py:371-379: back to the time domain
+        y = transform.synthesis(Y, framesize, framesize // 2, win=win_s)
     sir_out = output_sir(Y, X_mics, images, args.srcs)
     W0 = np.zeros((n_freq, args.mics, args.srcs), dtype=np.complex128)
     W0[:, : args.srcs, :] = np.eye(args.srcs)
@@ -121,8 +163,10 @@ def run(argv=None, verbose=True):
         print("Time for BSS: {:.2f} s".format(t_end - t_begin))   # overiva_oneshot.py:366-368
         print(f"output {Y.shape} {Y.dtype}; callback fired {len(trace)} times")
         print(f"SIR of the {args.srcs} strongest outputs: {sir_out:.1f} dB (first {args.srcs} microphones: {sir_in:.1f} dB)")
+        if y is not None:
+            print(f"separated audio {y.shape} {y.dtype} ({mics_signals.shape[0]} samples in)")
     return {"args": args, "X": X_mics, "images": images, "Y": Y, "trace": trace, "seconds": t_end - t_begin,
-            "sir_out": sir_out, "sir_in": sir_in}
+            "sir_out": sir_out, "sir_in": sir_in, "audio_in": mics_signals, "audio_out": y}
 
 
 if __name__ == "__main__":

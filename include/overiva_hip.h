@@ -174,6 +174,28 @@ int oiva_test_run_power(oiva_plan *p, float *p_host /* (T,K) summed over this pl
  * 3 update) on the plan's current state, HIP events on the plan's stream */
 int oiva_test_time_stage(oiva_plan *p, int stage, int reps, float *avg_ms);
 
+/*
+ * STFT analysis / synthesis on the GPU (hipFFT): time-domain audio in and out next to the solver.
+ * Replaces, in the reference's drivers, pra.transform.analysis(mics_signals.T, framesize, framesize // 2, win=win_a)
+ * (overiva_oneshot.py:293-295, overiva_sim.py:206-207) and pra.transform.synthesis(Y, framesize, framesize // 2,
+ * win=win_s) (overiva_oneshot.py:371-379).  Those are third-party pyroomacoustics calls whose source is absent from
+ * the reference: parity unpinned; the block-processing convention restated here: every frame holds `hop` new
+ * samples behind `frame - hop` old ones, zeros before the first sample, n_frames = n_samples / hop.
+ *   x (n_samples, n_chan) float32, C order  ->  X (n_frames, frame/2 + 1, n_chan) complex64
+ *   Y (n_frames, frame/2 + 1, k) complex64  ->  y (n_frames * hop, k) float32      (k <= n_chan)
+ * win_a / win_s: analysis / synthesis windows of `frame` floats, or NULL for a rectangular window.
+ * oiva_stft_analysis copies X to X_host when that is not NULL and returns, through X_dev when that is not NULL, the
+ * device array holding it (valid until the next analysis/synthesis on this handle): hand it to
+ * oiva_plan_set_x_dev to run the solver without a host round trip.  All calls are synchronous.
+ */
+typedef struct oiva_stft oiva_stft;
+int oiva_stft_create(oiva_stft **out, int device, int n_samples, int n_chan, int frame, int hop, const float *win_a,
+                     const float *win_s);
+int oiva_stft_destroy(oiva_stft *p);
+int oiva_stft_shape(oiva_stft *p, int *n_frames, int *n_freq);
+int oiva_stft_analysis(oiva_stft *p, const float *x_host, void *X_host, void **X_dev);
+int oiva_stft_synthesis(oiva_stft *p, const void *Y_host, int n_chan, float *y_host);
+
 #ifdef __cplusplus
 }
 #endif

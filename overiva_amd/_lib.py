@@ -65,6 +65,11 @@ SIGNATURES = {
     "oiva_test_set_what": [_vp, _vp, _i],
     "oiva_test_run_power": [_vp, _vp],
     "oiva_test_time_stage": [_vp, _i, _i, _fp],
+    "oiva_stft_create": [C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp],
+    "oiva_stft_destroy": [_vp],
+    "oiva_stft_shape": [_vp, C.POINTER(_i), C.POINTER(_i)],
+    "oiva_stft_analysis": [_vp, _vp, _vp, C.POINTER(_vp)],
+    "oiva_stft_synthesis": [_vp, _vp, _i, _vp],
 }
 
 

@@ -13,7 +13,7 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "liboveriva_hip.so")
-SOURCES = ["plan.hip", "kernels_cov.hip", "kernels_cov_gram.hip", "kernels_cov_mfma.hip", "kernels_demix.hip", "kernels_power_mfma.hip", "kernels_update.hip", "kernels_update16.hip", "kernels_misc.hip"]
+SOURCES = ["plan.hip", "kernels_cov.hip", "kernels_cov_gram.hip", "kernels_cov_mfma.hip", "kernels_demix.hip", "kernels_power_mfma.hip", "kernels_update.hip", "kernels_update16.hip", "kernels_misc.hip", "stft.hip"]
 HEADERS = [os.path.join(CSRC, "oiva_internal.h"), os.path.join(CSRC, "oiva_device.h"), os.path.join(REPO, "include", "overiva_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
@@ -60,7 +60,7 @@ def build_library(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if force or _stale(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lhipfft", "-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

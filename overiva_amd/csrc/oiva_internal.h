@@ -8,6 +8,9 @@
 
 namespace oiva {
 
+// records the thread-local message oiva_last_error() returns and hands back `code` (defined in plan.hip)
+int fail_with(int code, const std::string& msg);
+
 // ---- lane geometry shared by the streaming kernels -------------------------------------------
 // A wave is 16 bins x 4 frame phases: lane l -> bin (l & 15), phase (l >> 4).  The 16 bins of one
 // frame are 16*M*8 contiguous bytes of the native (T, F, M) complex64 tensor, so one wave touches

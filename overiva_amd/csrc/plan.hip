@@ -21,6 +21,12 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+}  // namespace
+
+int oiva::fail_with(int code, const std::string& msg) { return fail(code, msg); }
+
+namespace {
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \

@@ -32,6 +32,9 @@ def test_driver_runs_and_matches_the_oracle(driver, capsys, algo, dist, init):
     args, X, Y = out["args"], out["X"], out["Y"]
     K = 4 if algo == "auxiva" else 2
     assert Y.shape == (96, 2049, K) and Y.dtype == np.complex128 and np.all(np.isfinite(Y))
+    # audio in, audio out: the separated channels come back in the time domain (overiva_oneshot.py:371-379)
+    assert out["audio_in"].shape == (96 * 2048, 4) and out["audio_out"].shape == (96 * 2048, K)
+    assert np.all(np.isfinite(out["audio_out"]))
     assert len(out["trace"]) == 2 and out["seconds"] > 0
     # the same dispatch through the oracle
     ref = driver.separate(args, X, lambda X_, **kw: orc.overiva_staged(X_, **kw), orc.auxiva_pca_faithful, None)
@@ -43,6 +46,11 @@ def test_driver_runs_and_matches_the_oracle(driver, capsys, algo, dist, init):
     assert e < 1e-5
     # separation happened: the reference's own quality statement is an SIR improvement (overiva_oneshot.py:394-403)
     assert out["sir_out"] > out["sir_in"] + 10.0
+
+
+def test_stft_domain_scene(driver):
+    out = driver.run(["-a", "overiva", "-m", "5", "-s", "2", "-n", "20", "--frames", "64", "--domain", "stft"], verbose=False)
+    assert out["audio_out"] is None and out["Y"].shape == (64, 2049, 2) and out["sir_out"] > out["sir_in"] + 10.0
 
 
 def test_no_callback_flag(driver):
