@@ -175,6 +175,26 @@ int oiva_test_run_power(oiva_plan *p, float *p_host /* (T,K) summed over this pl
 int oiva_test_time_stage(oiva_plan *p, int stage, int reps, float *avg_ms);
 
 /*
+ * OGIVE -- orthogonally constrained independent vector extraction of ONE source by gradient steps, the reference's
+ * ive.py::ogive(X, n_iter, step_size, tol, update, proj_back, W0, model, init_eig, return_filters, callback)
+ * (ive.py:33-256; called at overiva_sim.py:313-315).  Runs on a plan created with K = 1 after oiva_plan_covariance
+ * and oiva_plan_set_w (w = column 0: identity start ive.py:129-130, or W0 / the principal eigenvector from the host):
+ *   oiva_plan_ogive_begin   : Cx^-1, ||Cx||, a from w, step selection                       ive.py:100-102,136-139,173-180
+ *   oiva_plan_ogive_iterate : up to n epochs of ive.py:190-246 starting at epoch index first_epoch (the switching
+ *                             criterion runs when the index is a multiple of 10).  The stopping rule max ||delta|| < tol
+ *                             is evaluated on the device after every epoch; once met the state is frozen and the
+ *                             remaining epochs of the call are no-ops.  Synchronous: returns the number of epochs that
+ *                             changed the state and whether the rule was met.
+ * The result is read with oiva_plan_demix / oiva_plan_get_w as for the other algorithms.
+ */
+#define OIVA_OGIVE_DEMIX 0
+#define OIVA_OGIVE_MIX 1
+#define OIVA_OGIVE_SWITCHING 2
+int oiva_plan_ogive_begin(oiva_plan *p, int update_mode, int model);
+int oiva_plan_ogive_iterate(oiva_plan *p, int first_epoch, int n, double step_size, double tol, int *epochs_run,
+                            int *converged, double *max_delta);
+
+/*
  * STFT analysis / synthesis on the GPU (hipFFT): time-domain audio in and out next to the solver.
  * Replaces, in the reference's drivers, pra.transform.analysis(mics_signals.T, framesize, framesize // 2, win=win_a)
  * (overiva_oneshot.py:293-295, overiva_sim.py:206-207) and pra.transform.synthesis(Y, framesize, framesize // 2,

@@ -65,6 +65,8 @@ SIGNATURES = {
     "oiva_test_set_what": [_vp, _vp, _i],
     "oiva_test_run_power": [_vp, _vp],
     "oiva_test_time_stage": [_vp, _i, _i, _fp],
+    "oiva_plan_ogive_begin": [_vp, _i, _i],
+    "oiva_plan_ogive_iterate": [_vp, _i, _i, C.c_double, C.c_double, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_double)],
     "oiva_stft_create": [C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp],
     "oiva_stft_destroy": [_vp],
     "oiva_stft_shape": [_vp, C.POINTER(_i), C.POINTER(_i)],

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void activation_kernel(const float* __restr
             for (int u = 0; u < 8; ++u) p += v[u];
         }
         for (; i < nparts; ++i) p += parts[(size_t)i * n + e];
-        r = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(p) : p * inv_f_total;
+        r = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(p) : (model == kModelOgiveLaplace ? sqrtf(p * inv_f_total) : p * inv_f_total);
         R[e] = r;
     }
     double s = (double)r;

@@ -171,6 +171,29 @@ hipError_t launch_demix_stats(hipStream_t s, const float2* X, const float2* What
 //   write Y (T,F,K) c64, scaled by conj(z) when Spart != nullptr
 hipError_t launch_demix_write(hipStream_t s, const float2* X, const float2* What, const float* Spart, int nsplit,
                               float2* Y, int T, int F, int M, int K);
+// OGIVE (ive.py:33-256): per-bin state and kernels (kernels_ogive.hip); the streaming passes are the AuxIVA ones
+struct OgiveState {
+    const double* Cx;    // [F][M*M] packed Hermitian, / T
+    double2* CxInv;      // (F, M, M) complex128
+    double* CxNorm;      // (F) Frobenius norm of Cx
+    double2* A;          // (F, M) mixing vector a
+    double2* Delta;      // (F, M) last step of every bin
+    double* Lambda;      // (F) lambda_a
+    int* DoA;            // (F) mixing-vector step selected
+    int* DoW;            // (F) demixing-vector step selected
+    double* Dnorm;       // (F) ||delta_f||
+    int* ctrl;           // [0] stopping rule met, [1] epochs run
+    double* maxdelta;    // [0] max_f ||delta_f|| of the last epoch
+    float2* What;        // (F, M, M): column 0 = w, what the streaming kernels read
+    double2* What64;     // complex128 copy
+};
+constexpr int kModelOgiveLaplace = 2;   // activation r = sqrt(p) / sqrt(F) (ive.py:210); OIVA_MODEL_GAUSS serves ive.py:213
+hipError_t launch_ogive_init(hipStream_t s, const OgiveState& st, int F, int M, int mode);
+hipError_t launch_ogive_switch(hipStream_t s, const OgiveState& st, int F, int M);
+hipError_t launch_ogive_step(hipStream_t s, const OgiveState& st, const void* Vpart, bool vpart_f64, int nsplit, int T, int F,
+                             int M, double mu);
+hipError_t launch_ogive_check(hipStream_t s, const OgiveState& st, int F, double tol);
+
 // unpack packed Hermitian float64 [nmat][M*M] -> full complex nmat x (M,M): complex64, or complex128 when out_f64
 hipError_t launch_unpack_herm(hipStream_t s, const double* packed, void* full, bool out_f64, long long nmat, int M);
 

@@ -81,6 +81,11 @@ struct oiva_plan {
     bool upd_f64() const { return prec & OIVA_PREC_UPDATE_F64; }
     bool cov_f64() const { return prec & OIVA_PREC_COV_F64; }
     int use_graph = 0;
+    // OGIVE (ive.py): per-bin state, allocated by oiva_plan_ogive_begin
+    OgiveState og{};
+    std::vector<void*> og_bufs;
+    bool og_ready = false;
+    int og_mode = 0, og_model = 0;
     hipGraphExec_t graph_exec = nullptr;        // one iteration
     hipGraphExec_t graph_batch_exec = nullptr;  // kGraphBatch iterations
     hipEvent_t ev[2] = {};
@@ -415,6 +420,8 @@ int oiva_plan_destroy(oiva_plan* p) {
                     p->R,       p->wscale, p->Spart, p->Y,      p->scratch_c, p->scratch_p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    for (void* b : p->og_bufs)
+        if (b) (void)hipFree(b);
     for (auto& ev : p->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
@@ -732,6 +739,80 @@ int oiva_plan_set_precision(oiva_plan* p, int flags) {
         choose_cov_geom(p, 0);            // sources per pass and residency depend on the accumulator type
         if ((rc = ensure_vpart(p))) return rc;
     }
+    return OIVA_OK;
+}
+
+// ---- OGIVE (reference ive.py:33-256) ----------------------------------------------------------------
+int oiva_plan_ogive_begin(oiva_plan* p, int update_mode, int model) {
+    int rc = check_ready(p);
+    if (rc) return rc;
+    NEED(p->K == 1, OIVA_ERR_ARG, "OGIVE extracts one source: create the plan with K = 1");
+    NEED(p->F == p->F_total, OIVA_ERR_STATE, "OGIVE is not bin-sharded");
+    NEED(update_mode >= OIVA_OGIVE_DEMIX && update_mode <= OIVA_OGIVE_SWITCHING, OIVA_ERR_ARG, "unknown update mode");
+    NEED(model == OIVA_MODEL_LAPLACE || model == OIVA_MODEL_GAUSS, OIVA_ERR_ARG, "unknown model");
+    DeviceGuard guard(p->device);
+    const size_t F = p->F, M = p->M;
+    if (p->og_bufs.empty()) {
+        hipError_t e = hipSuccess;
+        auto alloc = [&](size_t bytes) -> void* {
+            void* ptr = nullptr;
+            if (e == hipSuccess) e = hipMalloc(&ptr, bytes);
+            if (ptr) p->og_bufs.push_back(ptr);
+            return ptr;
+        };
+        p->og.CxInv = (double2*)alloc(F * M * M * sizeof(double2));
+        p->og.CxNorm = (double*)alloc(F * sizeof(double));
+        p->og.A = (double2*)alloc(F * M * sizeof(double2));
+        p->og.Delta = (double2*)alloc(F * M * sizeof(double2));
+        p->og.Lambda = (double*)alloc(F * sizeof(double));
+        p->og.DoA = (int*)alloc(F * sizeof(int));
+        p->og.DoW = (int*)alloc(F * sizeof(int));
+        p->og.Dnorm = (double*)alloc(F * sizeof(double));
+        p->og.ctrl = (int*)alloc(2 * sizeof(int));
+        p->og.maxdelta = (double*)alloc(sizeof(double));
+        if (e != hipSuccess) return fail(OIVA_ERR_HIP, std::string("allocation failed: ") + hipGetErrorString(e));
+    }
+    if (!p->what64_valid) {              // the step kernel reads and writes the complex128 copy of w
+        std::vector<double2> wh;
+        if ((rc = download_what(p, wh)) || (rc = upload_what(p, wh))) return rc;
+    }
+    p->og.Cx = p->Cx;
+    p->og.What = p->What;
+    p->og.What64 = p->What64;
+    p->og_mode = update_mode;
+    p->og_model = model;
+    HIP_TRY(launch_ogive_init(p->stream, p->og, p->F, p->M, update_mode));
+    p->og_ready = true;
+    return OIVA_OK;
+}
+
+int oiva_plan_ogive_iterate(oiva_plan* p, int first_epoch, int n, double step_size, double tol, int* epochs_run,
+                            int* converged, double* max_delta) {
+    int rc = check_ready(p);
+    if (rc) return rc;
+    NEED(p->og_ready, OIVA_ERR_STATE, "call oiva_plan_ogive_begin first");
+    NEED(n >= 0 && first_epoch >= 0, OIVA_ERR_ARG, "negative epoch count");
+    DeviceGuard guard(p->device);
+    int before[2] = {0, 0};
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(before, p->og.ctrl, sizeof(before), hipMemcpyDeviceToHost));
+    const int amodel = p->og_model == OIVA_MODEL_LAPLACE ? kModelOgiveLaplace : OIVA_MODEL_GAUSS;
+    for (int e = first_epoch; e < first_epoch + n; ++e) {
+        if (p->og_mode == OIVA_OGIVE_SWITCHING && e % 10 == 0) HIP_TRY(launch_ogive_switch(p->stream, p->og, p->F, p->M));   // ive.py:192-193
+        if ((rc = stage_power(p))) return rc;                                                   // ive.py:196 + the norm of :210/:213
+        HIP_TRY(launch_activation(p->stream, p->Ppart, p->pw.nb, p->R, p->T, 1, amodel, p->F));   // ive.py:209-217 (floor + 1/r in the consumer)
+        HIP_TRY(launch_cov(p->stream, p->X, p->R, p->Plocal, p->wscale, p->model, /*raw: weights 1 / max(r, eps)*/ 1, p->Vpart,
+                           p->cov_f64(), p->T, p->F, p->M, 1, p->cov));                        // ive.py:221-227
+        HIP_TRY(launch_ogive_step(p->stream, p->og, p->Vpart, p->cov_f64(), p->cov.nsplit, p->T, p->F, p->M, step_size));
+        HIP_TRY(launch_ogive_check(p->stream, p->og, p->F, tol));                                // ive.py:243-246
+    }
+    p->wscale_pending = false;
+    int after[2] = {0, 0};
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(after, p->og.ctrl, sizeof(after), hipMemcpyDeviceToHost));
+    if (epochs_run) *epochs_run = after[1] - before[1];
+    if (converged) *converged = after[0];
+    if (max_delta) HIP_TRY(hipMemcpy(max_delta, p->og.maxdelta, sizeof(double), hipMemcpyDeviceToHost));
     return OIVA_OK;
 }
 

@@ -113,6 +113,18 @@ class Plan:
     def update(self, parts_dev_ptr, nparts):
         _lib.check(self.lib.oiva_plan_update(self.h, C.c_void_p(int(parts_dev_ptr)), int(nparts)))
 
+    # -- OGIVE (reference ive.py) ------------------------------------------------------------------
+    def ogive_begin(self, update="demix", model="laplace"):
+        _lib.check(self.lib.oiva_plan_ogive_begin(self.h, {"demix": 0, "mix": 1, "switching": 2}[update],
+                                                  _lib.MODEL_IDS[model]))
+
+    def ogive_iterate(self, first_epoch, n, step_size=0.1, tol=1e-3):
+        """up to n epochs; returns (epochs that changed the state, stopping rule met, max ||delta|| of the last epoch)"""
+        ran, conv, md = C.c_int(), C.c_int(), C.c_double()
+        _lib.check(self.lib.oiva_plan_ogive_iterate(self.h, int(first_epoch), int(n), float(step_size), float(tol),
+                                                    C.byref(ran), C.byref(conv), C.byref(md)))
+        return ran.value, bool(conv.value), md.value
+
     def iterate_timed(self, n, per_kernel=False):
         total = C.c_float()
         if per_kernel:
