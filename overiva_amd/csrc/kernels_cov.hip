@@ -77,9 +77,8 @@ constexpr int kLdsStride = kBlock + 1;   // +1: conflict-free transposed read
 // Combine the 16 frame phases of a workgroup (tid = q*16 + b) in rounds of kChunk accumulators through
 // LDS and store one packed partial per (frame split, bin, source):
 //   write lds[a][tid]; thread (bb = tid/16, aa = tid%16) sums lds[aa][qq*16 + bb] over qq (fixed order).
-template <int M, int KC, typename ACC>
-__device__ __forceinline__ void reduce_and_store(const ACC (&acc)[KC][M * M], ACC* lds, ACC* __restrict__ Vpart,
-                                                 int F, int K, int k0) {
+template <int M, int KC, typename ACC, typename At>
+__device__ __forceinline__ void reduce_and_store_at(At&& at, ACC* lds, ACC* __restrict__ Vpart, int F, int K, int k0) {
     constexpr int NA = M * M;
     constexpr int NACC = NA * KC;
     const int tid = threadIdx.x;
@@ -91,7 +90,7 @@ __device__ __forceinline__ void reduce_and_store(const ACC (&acc)[KC][M * M], AC
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < kChunk; ++a) {
-            if (r0 + a < NACC) lds[a * kLdsStride + tid] = acc[(r0 + a) / NA][(r0 + a) % NA];
+            if (r0 + a < NACC) lds[a * kLdsStride + tid] = at(r0 + a);      // accumulator kk * NA + a, compile-time index
         }
         __syncthreads();
         ACC s = 0;
@@ -101,6 +100,12 @@ __device__ __forceinline__ void reduce_and_store(const ACC (&acc)[KC][M * M], AC
         const int kk = e / NA;          // constant-folded per round when NA % 16 == 0
         if (e < NACC && fo < F && k0 + kk < K) out[e] = s;
     }
+}
+
+template <int M, int KC, typename ACC>
+__device__ __forceinline__ void reduce_and_store(const ACC (&acc)[KC][M * M], ACC* lds, ACC* __restrict__ Vpart,
+                                                 int F, int K, int k0) {
+    reduce_and_store_at<M, KC, ACC>([&](int e) { return acc[e / (M * M)][e % (M * M)]; }, lds, Vpart, F, K, k0);
 }
 
 template <int M, int KC, bool UNIT, typename ACC>
@@ -194,6 +199,88 @@ __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Packed-fp32 arithmetic for two sources on natural (re, im) register pairs.  hipcc's own code for the generic
+// accumulate() spends a third of its VALU instructions on moves that assemble operand pairs (measured in the
+// ISA: 102 v_mov next to 146 v_pk_* per frame); VOP3P's op_sel / op_sel_hi / neg_hi modifiers make them
+// unnecessary: every operand is a pair exactly as ds_read_b128 delivered it.
+//   x_c conj(x_d) = (xr_c xr_d + xi_c xi_d,  xi_c xr_d - xr_c xi_d)
+//     p  = (xr_c * xr_d, -(xr_c * xi_d))            v_pk_mul  src0 lo broadcast, neg_hi on src1
+//     p += (xi_c * xi_d,   xi_c * xr_d)             v_pk_fma  src0 hi broadcast, src1 halves swapped
+//     V_k += w_k * p                                 v_pk_fma  w = (w_0, w_1) pair, lo | hi broadcast
+// ---------------------------------------------------------------------------------------------
+using v2f = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ v2f pk_mul_lo_negim(v2f a, v2f b) {          // (a.x * b.x, -(a.x * b.y))
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_fma_hi_swap(v2f a, v2f b, v2f c) {    // (c.x + a.y * b.y, c.y + a.y * b.x)
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ v2f pk_fma_w0(v2f w, v2f p, v2f c) {         // c + w.x * p
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(p), "v"(c));
+    return r;
+}
+__device__ __forceinline__ v2f pk_fma_w1(v2f w, v2f p, v2f c) {         // c + w.y * p
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(w), "v"(p), "v"(c));
+    return r;
+}
+
+// accumulators of TWO sources in that layout: off-diagonal entries as (re, im) pairs, diagonals as scalars
+template <int M>
+struct PkAcc2 {
+    static constexpr int NP = M * (M - 1) / 2;
+    v2f pair[2][NP];
+    float diag[2][M];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) pair[k][i] = v2f{0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < M; ++c) diag[k][c] = 0.f;
+        }
+    }
+    // x[c] = (re, im) of channel c; w = (w_0, w_1)
+    __device__ __forceinline__ void add(const v2f (&x)[M], v2f w) {
+#pragma unroll
+        for (int c = 0; c < M; ++c) {
+            const v2f sq = x[c] * x[c];
+            const float p = sq.x + sq.y;
+            diag[0][c] = fmaf(w.x, p, diag[0][c]);
+            diag[1][c] = fmaf(w.y, p, diag[1][c]);
+        }
+        // the compiler keeps inline asm in source order and knows no latencies: the products of a whole row are
+        // formed first (independent instructions back to back), then accumulated
+        int i0 = 0;
+#pragma unroll
+        for (int c = 0; c < M; ++c) {
+            v2f p[M];
+#pragma unroll
+            for (int d = c + 1; d < M; ++d) p[d] = pk_mul_lo_negim(x[c], x[d]);
+#pragma unroll
+            for (int d = c + 1; d < M; ++d) p[d] = pk_fma_hi_swap(x[c], x[d], p[d]);
+#pragma unroll
+            for (int d = c + 1; d < M; ++d) pair[0][i0 + d - c - 1] = pk_fma_w0(w, p[d], pair[0][i0 + d - c - 1]);
+#pragma unroll
+            for (int d = c + 1; d < M; ++d) pair[1][i0 + d - c - 1] = pk_fma_w1(w, p[d], pair[1][i0 + d - c - 1]);
+            i0 += M - c - 1;
+        }
+    }
+    // packed Hermitian layout (herm_pair_index): accumulator e = k * M*M + a
+    __device__ __forceinline__ float at(int e) const {
+        const int k = e / (M * M), a = e % (M * M);
+        if (a < M) return diag[k][a];
+        return ((a - M) & 1) ? pair[k][(a - M) >> 1].y : pair[k][(a - M) >> 1].x;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // LDS-DMA variant of the weighted pass (even M).  Same lane geometry and arithmetic as cov_kernel, but
 // X goes HBM -> LDS with global_load_lds (no staging registers) into a private 4-stage ring per wave:
 // three steps (3 * 64 lanes * M*8 bytes) stay in flight while the fourth is consumed, which is what a
@@ -262,11 +349,17 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
     const int t_end = min(T, t_begin + tc);
     const int nsteps = (t_end - t_begin + 15) >> 4;
 
-    float acc[KC][NA];
+    constexpr bool kPacked = KC == 2;            // two sources: hand-packed arithmetic on (re, im) pairs
+    float acc[kPacked ? 1 : KC][kPacked ? 1 : NA];
+    PkAcc2<M> pacc;
+    if constexpr (kPacked) {
+        pacc.clear();
+    } else {
 #pragma unroll
-    for (int kk = 0; kk < KC; ++kk)
+        for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
-        for (int a = 0; a < NA; ++a) acc[kk][a] = 0.f;
+            for (int a = 0; a < NA; ++a) acc[kk][a] = 0.f;
+    }
 
     float ginv[KC];
     float4* wring = ring + wave * kDmaStages * STAGE;                       // wave-uniform
@@ -303,15 +396,25 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
         }
         float4 v[PIECES];
         ring_read<PIECES>(rd_base + s * STAGE * 16, v);
-        float xr[M], xi[M];
+        if constexpr (kPacked) {
+            v2f x[M];
 #pragma unroll
-        for (int j = 0; j < PIECES; ++j) {
-            xr[2 * j] = v[j].x;
-            xi[2 * j] = v[j].y;
-            xr[2 * j + 1] = v[j].z;
-            xi[2 * j + 1] = v[j].w;
+            for (int j = 0; j < PIECES; ++j) {
+                x[2 * j] = v2f{v[j].x, v[j].y};
+                x[2 * j + 1] = v2f{v[j].z, v[j].w};
+            }
+            pacc.add(x, v2f{w[0], w[1]});
+        } else {
+            float xr[M], xi[M];
+#pragma unroll
+            for (int j = 0; j < PIECES; ++j) {
+                xr[2 * j] = v[j].x;
+                xi[2 * j] = v[j].y;
+                xr[2 * j + 1] = v[j].z;
+                xi[2 * j + 1] = v[j].w;
+            }
+            accumulate<M, KC, false, float>(acc, xr, xi, w);
         }
-        accumulate<M, KC, false, float>(acc, xr, xi, w);
     };
 
     issue(0, 0);
@@ -342,7 +445,12 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
     if (i + 2 < nsteps) { issue(i + 5, 1); consume(i + 2, 2); }
     // drain the DMA queue before the ring is reused as reduction scratch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    reduce_and_store<M, KC, float>(acc, reinterpret_cast<float*>(ring), Vpart, F, K, k0);
+    // (adding the 4 phases of a wave in registers first -- v_permlane16/32_swap, a quarter of the LDS traffic, 4
+    // barriers instead of 16 -- was measured slower: 102-104 us against 96-98)
+    if constexpr (kPacked)
+        reduce_and_store_at<M, KC, float>([&](int e) { return pacc.at(e); }, reinterpret_cast<float*>(ring), Vpart, F, K, k0);
+    else
+        reduce_and_store<M, KC, float>(acc, reinterpret_cast<float*>(ring), Vpart, F, K, k0);
 }
 
 template <typename ACC>
