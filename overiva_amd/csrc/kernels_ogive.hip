@@ -4,14 +4,13 @@
 // (ive.py:196, the norm of :210/:213), the activation (r = ||y|| / sqrt(F) | ||y||^2 / F, floor, :209-217) and the
 // weighted covariance V = (1/T) sum_t r_inv x x^H with K = 1, because
 //     X^T psi = sum_t r_inv x conj(y) = T V w     and     zeta = sum_t r_inv |y|^2 = T w^H V w      (ive.py:221-227)
-// so x_psi = V w / (w^H V w).  What is left per bin is a handful of M-vector operations -- one thread per bin,
-// float64 throughout (2049 bins x M <= 16: a few microseconds):
+// so x_psi = V w / (w^H V w).  What is left per bin is a handful of M-vector operations, float64 throughout:
 //     demixing step   delta = a - x_psi;  w += mu delta;  a = Cx w / Re(w^H Cx w)                    (:231-232, :136-139)
 //     mixing step     delta = w - lambda_a Cx^-1 x_psi;  a += mu delta;  w = lambda_a Cx^-1 a        (:236-237, :141-144)
 //     lambda_a = 1 / Re(a^H Cx^-1 a) is refreshed for EVERY bin in every epoch                       (:143)
 //     switching criterion every 10 epochs                                                             (:146-166)
-// and the stopping rule max_f ||delta_f|| < tol (:243-246): a one-block kernel raises a device flag after which the
-// step kernel leaves the state untouched, so the host may run epochs in chunks without a round trip per epoch.
+// and the stopping rule max_f ||delta_f|| < tol (:243-246): the step kernel raises a device flag after which it leaves
+// the state untouched, so the host may run epochs in chunks without a round trip per epoch.
 #include "oiva_internal.h"
 
 namespace oiva {
@@ -143,6 +142,9 @@ __global__ __launch_bounds__(64) void ogive_init_kernel(OgiveState st, int F, in
     if (f == 0) {
         st.ctrl[0] = 0;      // done
         st.ctrl[1] = 0;      // epochs run
+        st.ctrl[2] = 0;      // workgroups of the step kernel that have finished the current epoch
+        st.maxdelta[0] = 0.;
+        st.maxdelta[1] = 0.; // running max of ||delta_f|| (bit pattern) of the current epoch
     }
 }
 
@@ -184,92 +186,138 @@ __global__ __launch_bounds__(64) void ogive_switch_kernel(OgiveState st, int F, 
     st.DoW[f] = kappa < 0.1 ? 1 : 0;
 }
 
-// one epoch of the per-bin part, ive.py:221-241
+// one epoch of the per-bin part, ive.py:221-241, and the stopping rule max_f ||delta_f|| < tol (ive.py:243-246).
+// MP lanes per bin (MP = channels rounded up to 4 | 8 | 16): lane i owns row i of every matrix-vector product and
+// entry i of w, a, x_psi, delta; vectors and the terms of the scalar products are exchanged through LDS and summed by
+// every lane in index order, so the arithmetic is the sequential one of the restatement.  The last workgroup to finish
+// (ticket counter) folds the per-workgroup maxima into the stop flag -- no separate reduction launch.
+template <int MP>
 __global__ __launch_bounds__(64) void ogive_step_kernel(OgiveState st, const void* __restrict__ Vpart, int vpart_f64, int nsplit,
-                                                        int T, int F, int M, double mu) {
-    const int f = blockIdx.x * 64 + threadIdx.x;
-    if (f >= F || st.ctrl[0]) return;
+                                                        int T, int F, int M, double mu, double tol) {
+    constexpr int kBins = 64 / MP;
+    __shared__ Z sv[kBins][MP];
+    __shared__ double sr[kBins][MP];
+    __shared__ double sdn[kBins];
+    if (st.ctrl[0]) return;                                              // grid-uniform: the rule was met in an earlier epoch
+    const int g = threadIdx.x / MP, i = threadIdx.x % MP;
+    const int fraw = blockIdx.x * kBins + g;
+    const bool live = fraw < F && i < M;
+    const int f = fraw < F ? fraw : F - 1, ic = i < M ? i : M - 1;      // padding lanes shadow a real one and store nothing
     const int NA = M * M;
-    const double* cx = st.Cx + (size_t)f * NA;
-    const double2* Ci = st.CxInv + (size_t)f * NA;
-    // V (packed Hermitian, K = 1): fixed-order sum of the frame-split partials, / T
-    double v[MX * MX];
-    for (int e = 0; e < NA; ++e) {
+    auto sum_seq = [&](double term) {                                    // sum_j term_j, j ascending, on every lane of the bin
+        __syncthreads();
+        sr[g][i] = term;
+        __syncthreads();
         double s = 0.;
-        for (int sp = 0; sp < nsplit; ++sp) s += load_vpart(Vpart, vpart_f64, ((size_t)sp * F + f) * NA + e);
-        v[e] = s / (double)T;
-    }
-    Z w[MX], a[MX], xpsi[MX], dl[MX], tmp[MX];
-    load_w(st, f, M, w);
-    double den = 0.;
-    for (int i = 0; i < M; ++i) {
+#pragma unroll
+        for (int j = 0; j < MP; ++j)
+            if (j < M) s += sr[g][j];
+        return s;
+    };
+    auto share = [&](Z v) {
+        __syncthreads();
+        sv[g][i] = v;
+        __syncthreads();
+    };
+    // row ic of a packed Hermitian matrix times the shared vector
+    auto herm_row_times = [&](auto&& entry) {
         Z s = {0., 0.};
-        for (int j = 0; j < M; ++j) zacc(s, herm_at(v, M, i, j), w[j]);
-        xpsi[i] = s;
-        den += w[i].re * s.re + w[i].im * s.im;                          // w^H V w is real
-        a[i] = {st.A[(size_t)f * M + i].x, st.A[(size_t)f * M + i].y};
-    }
-    for (int i = 0; i < M; ++i) xpsi[i] = {xpsi[i].re / den, xpsi[i].im / den};
+#pragma unroll
+        for (int j = 0; j < MP; ++j)
+            if (j < M) zacc(s, entry(j), sv[g][j]);
+        return s;
+    };
+    auto packed_entry = [&](auto&& load, int j) -> Z {                   // entry (ic, j); load(e) reads packed slot e
+        if (j == ic) return {load(ic), 0.};
+        const int lo = j < ic ? j : ic, hi = j < ic ? ic : j;
+        const int o = herm_pair_index(M, lo, hi);
+        const double re = load(o), im = load(o + 1);
+        return {re, j < ic ? -im : im};
+    };
+    const double2 w0 = st.What64[((size_t)f * M + ic) * M], a0 = st.A[(size_t)f * M + ic];
+    Z w = {w0.x, w0.y}, a = {a0.x, a0.y};
     const bool do_a = st.DoA[f] != 0, do_w = st.DoW[f] != 0;
-    double dn = -1.;
-    if (do_w) {                                                          // ive.py:231-232, then :240 -> :136-139
-        for (int m = 0; m < M; ++m) {
-            dl[m] = {a[m].re - xpsi[m].re, a[m].im - xpsi[m].im};
-            w[m] = {w[m].re + mu * dl[m].re, w[m].im + mu * dl[m].im};
-        }
-        a_from_w(cx, M, w, a);
+    // x_psi = V w / (w^H V w); V: fixed-order sum of the frame-split partials, / T
+    share(w);
+    Z xpsi = herm_row_times([&](int j) {
+        return packed_entry(
+            [&](int e) {
+                double s = 0.;
+                for (int sp = 0; sp < nsplit; ++sp) s += load_vpart(Vpart, vpart_f64, ((size_t)sp * F + f) * NA + e);
+                return s / (double)T;
+            },
+            j);
+    });
+    const double den = sum_seq(w.re * xpsi.re + w.im * xpsi.im);        // w^H V w is real
+    xpsi = {xpsi.re / den, xpsi.im / den};
+    const double* cx = st.Cx + (size_t)f * NA;
+    const double2* Ci = st.CxInv + ((size_t)f * M + ic) * M;
+    auto inv_row_times = [&]() {                                         // row ic of Cx^-1 times the shared vector
+        Z s = {0., 0.};
+#pragma unroll
+        for (int j = 0; j < MP; ++j)
+            if (j < M) zacc(s, Z{Ci[j].x, Ci[j].y}, sv[g][j]);
+        return s;
+    };
+    Z dl = {0., 0.};
+    if (do_w) {                                                          // ive.py:231-232
+        dl = {a.re - xpsi.re, a.im - xpsi.im};
+        w = {w.re + mu * dl.re, w.im + mu * dl.im};
+    }
+    share(do_w ? w : xpsi);
+    Z t = {0., 0.};
+    if (do_w) {                                                          // ive.py:240 -> :136-139: a = Cx w / Re(w^H Cx w)
+        t = herm_row_times([&](int j) { return packed_entry([&](int e) { return cx[e]; }, j); });
     } else if (do_a) {                                                   // ive.py:236-237
+        t = inv_row_times();
         const double la = st.Lambda[f];
-        apply_inv(Ci, M, xpsi, tmp);
-        for (int m = 0; m < M; ++m) {
-            dl[m] = {w[m].re - tmp[m].re * la, w[m].im - tmp[m].im * la};
-            a[m] = {a[m].re + mu * dl[m].re, a[m].im + mu * dl[m].im};
-        }
+        dl = {w.re - t.re * la, w.im - t.im * la};
+        a = {a.re + mu * dl.re, a.im + mu * dl.im};
     }
-    if (do_w || do_a) {
-        dn = 0.;
-        for (int m = 0; m < M; ++m) {
-            dn += dl[m].re * dl[m].re + dl[m].im * dl[m].im;
-            st.Delta[(size_t)f * M + m] = make_double2(dl[m].re, dl[m].im);
-        }
-        dn = sqrt(dn);
+    const double wcw = sum_seq(do_w ? w.re * t.re + w.im * t.im : 0.);
+    if (do_w) {
+        const double l = 1.0 / wcw;
+        a = {t.re * l, t.im * l};
     }
+    const double dsq = sum_seq(dl.re * dl.re + dl.im * dl.im);
+    const bool stepped = do_w || do_a;
     // lambda_a = 1 / Re(a^H Cx^-1 a) for every bin, w = lambda_a Cx^-1 a where the mixing step ran (ive.py:141-144)
-    apply_inv(Ci, M, a, tmp);
-    double q = 0.;
-    for (int m = 0; m < M; ++m) q += a[m].re * tmp[m].re + a[m].im * tmp[m].im;
-    const double la = 1.0 / q;
-    st.Lambda[f] = la;
-    if (do_a)
-        for (int m = 0; m < M; ++m) w[m] = {tmp[m].re * la, tmp[m].im * la};
-    for (int m = 0; m < M; ++m) st.A[(size_t)f * M + m] = make_double2(a[m].re, a[m].im);
-    store_w(st, f, M, w);
-    if (dn >= 0.) st.Dnorm[f] = dn;                                      // bins without a step keep their last delta
-}
-
-// max_f ||delta_f|| < tol -> done (ive.py:243-246); one block
-__global__ __launch_bounds__(kBlock) void ogive_check_kernel(OgiveState st, int F, double tol) {
-    __shared__ double red[kBlock];
-    if (st.ctrl[0]) return;
-    double m = 0.;
-    bool nan = false;
-    for (int f = threadIdx.x; f < F; f += kBlock) {
-        const double d = st.Dnorm[f];
-        nan = nan || !(d == d);
-        m = d > m ? d : m;
+    share(a);
+    t = inv_row_times();
+    const double la = 1.0 / sum_seq(a.re * t.re + a.im * t.im);
+    if (do_a) w = {t.re * la, t.im * la};
+    double dn = stepped ? sqrt(dsq) : st.Dnorm[f];                       // bins without a step keep their last delta
+    if (live) {
+        st.A[(size_t)f * M + i] = make_double2(a.re, a.im);
+        st.What64[((size_t)f * M + i) * M] = make_double2(w.re, w.im);
+        st.What[((size_t)f * M + i) * M] = make_float2((float)w.re, (float)w.im);
+        if (stepped) st.Delta[(size_t)f * M + i] = make_double2(dl.re, dl.im);
+        if (i == 0) {
+            st.Lambda[f] = la;
+            if (stepped) st.Dnorm[f] = dn;
+        }
     }
-    red[threadIdx.x] = nan ? __builtin_nan("") : m;
+    // stopping rule: a non-negative double orders like its bit pattern and every NaN sorts above +inf, which is numpy's
+    // rule too (the max of an array holding NaN is NaN, NaN < tol is False)
+    if (i == 0) sdn[g] = fraw < F ? dn : 0.;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double mx = 0.;
-        bool bad = false;
-        for (int i = 0; i < kBlock; ++i) {
-            bad = bad || !(red[i] == red[i]);
-            mx = red[i] > mx ? red[i] : mx;
+        unsigned long long top = 0;
+        for (int k = 0; k < kBins; ++k) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(sdn[k]) & 0x7fffffffffffffffull;
+            top = bits > top ? bits : top;
         }
-        st.ctrl[1] += 1;
-        st.maxdelta[0] = bad ? __builtin_nan("") : mx;
-        if (!bad && mx < tol) st.ctrl[0] = 1;          // numpy: max of an array holding NaN is NaN, NaN < tol is False
+        unsigned long long* slot = reinterpret_cast<unsigned long long*>(st.maxdelta + 1);
+        atomicMax(slot, top);
+        __threadfence();
+        if (atomicAdd(reinterpret_cast<unsigned int*>(st.ctrl + 2), 1u) == gridDim.x - 1) {
+            __threadfence();
+            const double mx = __longlong_as_double((long long)atomicExch(slot, 0ull));
+            st.ctrl[2] = 0;
+            st.ctrl[1] += 1;
+            st.maxdelta[0] = mx;
+            if (mx < tol) st.ctrl[0] = 1;
+        }
     }
 }
 
@@ -284,12 +332,13 @@ hipError_t launch_ogive_switch(hipStream_t s, const OgiveState& st, int F, int M
     return hipGetLastError();
 }
 hipError_t launch_ogive_step(hipStream_t s, const OgiveState& st, const void* Vpart, bool vpart_f64, int nsplit, int T, int F,
-                             int M, double mu) {
-    hipLaunchKernelGGL(ogive_step_kernel, dim3((F + 63) / 64), dim3(64), 0, s, st, Vpart, vpart_f64 ? 1 : 0, nsplit, T, F, M, mu);
-    return hipGetLastError();
-}
-hipError_t launch_ogive_check(hipStream_t s, const OgiveState& st, int F, double tol) {
-    hipLaunchKernelGGL(ogive_check_kernel, dim3(1), dim3(kBlock), 0, s, st, F, tol);
+                             int M, double mu, double tol) {
+    const int mp = M <= 4 ? 4 : (M <= 8 ? 8 : 16);
+    const dim3 grid((F + 64 / mp - 1) / (64 / mp));
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(64), 0, s, st, Vpart, vpart_f64 ? 1 : 0, nsplit, T, F, M, mu, tol); };
+    if (mp == 4) go(ogive_step_kernel<4>);
+    else if (mp == 8) go(ogive_step_kernel<8>);
+    else go(ogive_step_kernel<16>);
     return hipGetLastError();
 }
 

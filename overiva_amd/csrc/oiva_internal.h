@@ -182,8 +182,8 @@ struct OgiveState {
     int* DoA;            // (F) mixing-vector step selected
     int* DoW;            // (F) demixing-vector step selected
     double* Dnorm;       // (F) ||delta_f||
-    int* ctrl;           // [0] stopping rule met, [1] epochs run
-    double* maxdelta;    // [0] max_f ||delta_f|| of the last epoch
+    int* ctrl;           // [0] stopping rule met, [1] epochs run, [2] step-kernel workgroups done this epoch
+    double* maxdelta;    // [0] max_f ||delta_f|| of the last epoch, [1] running max of the current one (bit pattern)
     float2* What;        // (F, M, M): column 0 = w, what the streaming kernels read
     double2* What64;     // complex128 copy
 };
@@ -191,8 +191,7 @@ constexpr int kModelOgiveLaplace = 2;   // activation r = sqrt(p) / sqrt(F) (ive
 hipError_t launch_ogive_init(hipStream_t s, const OgiveState& st, int F, int M, int mode);
 hipError_t launch_ogive_switch(hipStream_t s, const OgiveState& st, int F, int M);
 hipError_t launch_ogive_step(hipStream_t s, const OgiveState& st, const void* Vpart, bool vpart_f64, int nsplit, int T, int F,
-                             int M, double mu);
-hipError_t launch_ogive_check(hipStream_t s, const OgiveState& st, int F, double tol);
+                             int M, double mu, double tol);
 
 // unpack packed Hermitian float64 [nmat][M*M] -> full complex nmat x (M,M): complex64, or complex128 when out_f64
 hipError_t launch_unpack_herm(hipStream_t s, const double* packed, void* full, bool out_f64, long long nmat, int M);

@@ -86,6 +86,10 @@ struct oiva_plan {
     std::vector<void*> og_bufs;
     bool og_ready = false;
     int og_mode = 0, og_model = 0;
+    // captured chunk of OGIVE epochs (five launches per epoch are latency bound on the reference's problem sizes)
+    hipGraphExec_t og_graph = nullptr;
+    int og_graph_n = 0, og_graph_phase = -1;
+    double og_graph_mu = 0., og_graph_tol = 0.;
     hipGraphExec_t graph_exec = nullptr;        // one iteration
     hipGraphExec_t graph_batch_exec = nullptr;  // kGraphBatch iterations
     hipEvent_t ev[2] = {};
@@ -183,6 +187,10 @@ int drop_graph(oiva_plan* p) {
     if (p->graph_batch_exec) {
         HIP_TRY(hipGraphExecDestroy(p->graph_batch_exec));
         p->graph_batch_exec = nullptr;
+    }
+    if (p->og_graph) {
+        HIP_TRY(hipGraphExecDestroy(p->og_graph));
+        p->og_graph = nullptr;
     }
     return OIVA_OK;
 }
@@ -416,6 +424,7 @@ int oiva_plan_destroy(oiva_plan* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->graph_batch_exec) (void)hipGraphExecDestroy(p->graph_batch_exec);
+    if (p->og_graph) (void)hipGraphExecDestroy(p->og_graph);
     void* bufs[] = {p->X_owned, p->What, p->What64, p->Cx,        p->Vpart,    p->Ppart, p->Plocal,
                     p->R,       p->wscale, p->Spart, p->Y,      p->scratch_c, p->scratch_p};
     for (void* b : bufs)
@@ -768,8 +777,8 @@ int oiva_plan_ogive_begin(oiva_plan* p, int update_mode, int model) {
         p->og.DoA = (int*)alloc(F * sizeof(int));
         p->og.DoW = (int*)alloc(F * sizeof(int));
         p->og.Dnorm = (double*)alloc(F * sizeof(double));
-        p->og.ctrl = (int*)alloc(2 * sizeof(int));
-        p->og.maxdelta = (double*)alloc(sizeof(double));
+        p->og.ctrl = (int*)alloc(4 * sizeof(int));
+        p->og.maxdelta = (double*)alloc(2 * sizeof(double));
         if (e != hipSuccess) return fail(OIVA_ERR_HIP, std::string("allocation failed: ") + hipGetErrorString(e));
     }
     if (!p->what64_valid) {              // the step kernel reads and writes the complex128 copy of w
@@ -797,14 +806,48 @@ int oiva_plan_ogive_iterate(oiva_plan* p, int first_epoch, int n, double step_si
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemcpy(before, p->og.ctrl, sizeof(before), hipMemcpyDeviceToHost));
     const int amodel = p->og_model == OIVA_MODEL_LAPLACE ? kModelOgiveLaplace : OIVA_MODEL_GAUSS;
-    for (int e = first_epoch; e < first_epoch + n; ++e) {
-        if (p->og_mode == OIVA_OGIVE_SWITCHING && e % 10 == 0) HIP_TRY(launch_ogive_switch(p->stream, p->og, p->F, p->M));   // ive.py:192-193
-        if ((rc = stage_power(p))) return rc;                                                   // ive.py:196 + the norm of :210/:213
-        HIP_TRY(launch_activation(p->stream, p->Ppart, p->pw.nb, p->R, p->T, 1, amodel, p->F));   // ive.py:209-217 (floor + 1/r in the consumer)
-        HIP_TRY(launch_cov(p->stream, p->X, p->R, p->Plocal, p->wscale, p->model, /*raw: weights 1 / max(r, eps)*/ 1, p->Vpart,
-                           p->cov_f64(), p->T, p->F, p->M, 1, p->cov));                        // ive.py:221-227
-        HIP_TRY(launch_ogive_step(p->stream, p->og, p->Vpart, p->cov_f64(), p->cov.nsplit, p->T, p->F, p->M, step_size));
-        HIP_TRY(launch_ogive_check(p->stream, p->og, p->F, tol));                                // ive.py:243-246
+    auto epochs = [&](int e0, int count) -> int {
+        for (int e = e0; e < e0 + count; ++e) {
+            if (p->og_mode == OIVA_OGIVE_SWITCHING && e % 10 == 0) HIP_TRY(launch_ogive_switch(p->stream, p->og, p->F, p->M));   // ive.py:192-193
+            int r = stage_power(p);                                                             // ive.py:196 + the norm of :210/:213
+            if (r) return r;
+            HIP_TRY(launch_activation(p->stream, p->Ppart, p->pw.nb, p->R, p->T, 1, amodel, p->F));   // ive.py:209-217 (floor + 1/r in the consumer)
+            HIP_TRY(launch_cov(p->stream, p->X, p->R, p->Plocal, p->wscale, p->model, /*raw: weights 1 / max(r, eps)*/ 1, p->Vpart,
+                               p->cov_f64(), p->T, p->F, p->M, 1, p->cov));                    // ive.py:221-227
+            HIP_TRY(launch_ogive_step(p->stream, p->og, p->Vpart, p->cov_f64(), p->cov.nsplit, p->T, p->F, p->M, step_size,
+                                      tol));                                                     // ive.py:228-246
+        }
+        return OIVA_OK;
+    };
+    constexpr int kMinGraphEpochs = 8;
+    if (n >= kMinGraphEpochs) {
+        // a chunk of n epochs as one hipGraph, cached while (n, position in the 10-epoch switching cadence, step
+        // size, tolerance) stay the same -- the usual case: the host runs equal chunks until the rule is met
+        const int phase = first_epoch % 10;
+        if (!p->og_graph || p->og_graph_n != n || p->og_graph_phase != phase || p->og_graph_mu != step_size ||
+            p->og_graph_tol != tol) {
+            if (p->og_graph) HIP_TRY(hipGraphExecDestroy(p->og_graph));
+            p->og_graph = nullptr;
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+            rc = epochs(phase, n);
+            hipError_t e = hipStreamEndCapture(p->stream, &graph);
+            if (rc) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
+            HIP_TRY(e);
+            e = hipGraphInstantiate(&p->og_graph, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            HIP_TRY(e);
+            p->og_graph_n = n;
+            p->og_graph_phase = phase;
+            p->og_graph_mu = step_size;
+            p->og_graph_tol = tol;
+        }
+        HIP_TRY(hipGraphLaunch(p->og_graph, p->stream));
+    } else if ((rc = epochs(first_epoch, n))) {
+        return rc;
     }
     p->wscale_pending = false;
     int after[2] = {0, 0};
