@@ -86,4 +86,53 @@ struct Mfma<double> {
     static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }   // NOT the fp32 map
 };
 
+// ---- register-level lane exchanges (no LDS crossbar): DPP within 16-lane rows, v_permlane{16,32}_swap
+//      across rows.  Values wider than 32 bits go through them one dword at a time. ----
+template <int CTRL>
+__device__ __forceinline__ int dpp32(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) { return __int_as_float(dpp32<CTRL>(__float_as_int(v))); }
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp(unsigned v) { return (unsigned)dpp32<CTRL>((int)v); }
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+    return __hiloint2double(dpp32<CTRL>(__double2hiint(v)), dpp32<CTRL>(__double2loint(v)));
+}
+constexpr int kDppXor1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;   // quad_perm [2,3,0,1]
+constexpr int kDppRor4 = 0x124;  // row_ror:4
+constexpr int kDppRor8 = 0x128;  // row_ror:8
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane l <-> 7 - l inside each group of 8
+// a + b where b is the value of the lane 16 (32) lanes away: the swap of a register with itself
+// leaves {own row pair member, other row pair member} in the two results
+__device__ __forceinline__ float swapsum16(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swapsum32(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ double swapsum16(double v) {
+    auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double swapsum32(double v) {
+    auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ unsigned swapmax16(unsigned v) {
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return r[0] > r[1] ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned swapmax32(unsigned v) {
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return r[0] > r[1] ? r[0] : r[1];
+}
+
+
 }  // namespace oiva

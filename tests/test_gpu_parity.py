@@ -317,7 +317,8 @@ def test_auxiva_pca(oa, golden):
 
 
 @pytest.mark.parametrize("shape", [(96, 5, 11, 3), (80, 3, 9, 9), (72, 6, 13, 1), (64, 4, 16, 5), (50, 7, 7, 7), (90, 19, 5, 2),
-                                   (90, 21, 8, 3), (64, 9, 8, 4), (70, 5, 8, 5), (100, 12, 8, 8), (60, 7, 7, 4)])
+                                   (90, 21, 8, 3), (64, 9, 8, 4), (70, 5, 8, 5), (100, 12, 8, 8), (60, 7, 7, 4), (64, 5, 12, 12),
+                                   (70, 4, 16, 16), (60, 3, 10, 10), (66, 2, 15, 15)])
 def test_odd_shapes_against_oracle(oa, shape):
     """channel counts without a golden fixture (incl. the matrix-core covariance path, 9..16 channels)"""
     T, F, M, K = shape
