@@ -13,86 +13,125 @@ namespace {
 
 constexpr int kBinsPerBatch = kBinsPerWave * kWaves;   // 64: same batches (and Ppart layout) as power_kernel
 
-constexpr int kFrameTiles = 4;       // 16-frame tiles per wave: the W operands of a bin are loaded once for 64 frames
-
-__global__ __launch_bounds__(kBlock) void power_mfma_kernel(const float2* __restrict__ X, const float2* __restrict__ What,
-                                                            float* __restrict__ Ppart, int T, int F, int M, int K) {
+// One wave = 16 x TILES frames x the 64 bins of a batch, in groups of GROUP bins.  The operands of a whole group are
+// requested at once -- per frame row one contiguous run of GROUP x M x 8 bytes -- and two further groups are in flight
+// while the MFMAs of this one run.  The contraction order is free, so lane (j, q) takes the four CONSECUTIVE channels
+// m = 4q + c, c = 0..3, as its share of the four chunks: its 32 bytes of a frame are two 16-byte loads (a chunk of every
+// fourth channel would be four 8-byte loads 32 bytes apart).
+template <bool VEC, int TILES, int GROUP>   // VEC: channels a multiple of 4, rows start and end on 16-byte boundaries
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void power_mfma_kernel(
+    const float2* __restrict__ X, const float2* __restrict__ What, float* __restrict__ Ppart, int T, int F, int M, int K) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int j = lane & 15;             // A: source (row) | B: frame (column)
-    const int q = lane >> 4;             // channel within the chunk of 4 (contraction index)
-    const int t0 = (blockIdx.y * kWaves + wave) * 16 * kFrameTiles + j;
+    const int q = lane >> 4;             // owner of channels 4q .. 4q + 3 (contraction index)
+    const int t0 = (blockIdx.y * kWaves + wave) * 16 * TILES + j;
     const int f0 = blockIdx.x * kBinsPerBatch;
     const int nbins = min(kBinsPerBatch, F - f0);
-    const int nchunks = (M + 3) >> 2;
-
-    float P[kFrameTiles][4];             // sources 4q..4q+3 at frame t0 + 16 * tile
-    const float2* px[kFrameTiles];
-    float tmask[kFrameTiles];
-    const size_t frame_stride = (size_t)F * M;
+    // frames past T and channels past M read a valid (clamped) address: the first are never stored, the second meet a
+    // zero in W
+    const float2* px[TILES];
 #pragma unroll
-    for (int tl = 0; tl < kFrameTiles; ++tl) {
+    for (int tl = 0; tl < TILES; ++tl) {
         const int t = t0 + 16 * tl;
-        tmask[tl] = t < T ? 1.f : 0.f;
-        px[tl] = X + (size_t)(t < T ? t : T - 1) * frame_stride + (size_t)f0 * M;   // + b*M + m
+        px[tl] = X + ((size_t)(t < T ? t : T - 1) * F + f0) * M + (4 * q < M ? 4 * q : 0);   // + b*M (+ c)
+    }
+    const float2* pw = What + (size_t)f0 * M * M;                                            // + (b*M + m)*M + k
+    float P[TILES][4];                   // sources 4q..4q+3 at frame t0 + 16 tl
+#pragma unroll
+    for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
         for (int r = 0; r < 4; ++r) P[tl][r] = 0.f;
-    }
-    const float2* pw = What + (size_t)f0 * M * M;                                   // + (b*M + m)*M + k
 
-    // operands of one bin: chunk c holds channel m = 4c + q; zero outside M x K
-    auto fetch_w = [&](int b, float2 (&w)[4]) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int m = 4 * c + q;
-            const bool ok = m < M && j < K;
-            const float2 wv = pw[((size_t)b * M + (m < M ? m : 0)) * M + (j < K ? j : 0)];
-            w[c] = make_float2(ok ? wv.x : 0.f, ok ? wv.y : 0.f);
-        }
+    struct Ops {
+        float2 w[GROUP][4];
+        float2 x[TILES][GROUP][4];
     };
-    auto fetch_x = [&](int b, float2 (&x)[kFrameTiles][4]) {
+    auto fetch = [&](int b0, Ops& o) {
 #pragma unroll
-        for (int tl = 0; tl < kFrameTiles; ++tl)
+        for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int m = 4 * c + q;
-                x[tl][c] = px[tl][(size_t)b * M + (m < M ? m : 0)];
-            }
-    };
-    float2 w[4], wn[4], x[kFrameTiles][4], xn[kFrameTiles][4];
-    fetch_w(0, w);
-    fetch_x(0, x);
-    for (int b = 0; b < nbins; ++b) {
-        const int bn = b + 1 < nbins ? b + 1 : b;
-        fetch_w(bn, wn);                 // next bin's operands are in flight during the MFMAs
-        fetch_x(bn, xn);
+            for (int g = 0; g < GROUP; ++g) {
+                const int b = b0 + g < nbins ? b0 + g : nbins - 1;
+                if constexpr (VEC) {
+                    const float4* p = reinterpret_cast<const float4*>(px[tl] + (size_t)b * M);
+                    const float4 lo = p[0], hi = p[1];
+                    o.x[tl][g][0] = make_float2(lo.x, lo.y);
+                    o.x[tl][g][1] = make_float2(lo.z, lo.w);
+                    o.x[tl][g][2] = make_float2(hi.x, hi.y);
+                    o.x[tl][g][3] = make_float2(hi.z, hi.w);
+                } else {
 #pragma unroll
-        for (int tl = 0; tl < kFrameTiles; ++tl) {
-            f32x4 yr = {0.f, 0.f, 0.f, 0.f}, yi = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c < nchunks) {
-                    const float xm = (4 * c + q < M) ? tmask[tl] : 0.f;
-                    const float xr = x[tl][c].x * xm, xi = x[tl][c].y * xm;
-                    yr = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].x, xr, yr, 0, 0, 0);
-                    yi = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].x, xi, yi, 0, 0, 0);
-                    yr = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].y, xi, yr, 0, 0, 0);
-                    yi = __builtin_amdgcn_mfma_f32_16x16x4f32(-w[c].y, xr, yi, 0, 0, 0);
+                    for (int c = 0; c < 4; ++c) o.x[tl][g][c] = px[tl][(size_t)b * M + (4 * q + c < M ? c : 0)];
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) P[tl][r] = fmaf(yr[r], yr[r], fmaf(yi[r], yi[r], P[tl][r]));
+        for (int g = 0; g < GROUP; ++g) {
+            const int b = b0 + g < nbins ? b0 + g : nbins - 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int m = 4 * q + c;
+                const bool ok = m < M && j < K && b0 + g < nbins;     // bins past the batch contribute nothing
+                const float2 wv = pw[((size_t)b * M + (m < M ? m : 0)) * M + (j < K ? j : 0)];
+                o.w[g][c] = make_float2(ok ? wv.x : 0.f, ok ? wv.y : 0.f);
+            }
+        }
+    };
+    // chunk-major over the tiles and bins of the group: 2 x TILES x GROUP independent accumulators, so an MFMA never
+    // waits for the result of the one issued just before it
+    auto compute = [&](const Ops& o) {
+        f32x4 yr[TILES][GROUP], yi[TILES][GROUP];
+#pragma unroll
+        for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+            for (int g = 0; g < GROUP; ++g) yr[tl][g] = yi[tl][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+                for (int g = 0; g < GROUP; ++g) {
+                    yr[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w[g][c].x, o.x[tl][g][c].x, yr[tl][g], 0, 0, 0);
+                    yi[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w[g][c].x, o.x[tl][g][c].y, yi[tl][g], 0, 0, 0);
+                }
+#pragma unroll
+            for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+                for (int g = 0; g < GROUP; ++g) {
+                    yr[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w[g][c].y, o.x[tl][g][c].y, yr[tl][g], 0, 0, 0);
+                    yi[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(-o.w[g][c].y, o.x[tl][g][c].x, yi[tl][g], 0, 0, 0);
+                }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) w[c] = wn[c];
+        for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
-        for (int tl = 0; tl < kFrameTiles; ++tl)
+            for (int g = 0; g < GROUP; ++g)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) x[tl][c] = xn[tl][c];
+                for (int r = 0; r < 4; ++r) P[tl][r] = fmaf(yr[tl][g][r], yr[tl][g][r], fmaf(yi[tl][g][r], yi[tl][g][r], P[tl][r]));
+    };
+    // Two groups in flight behind the one being multiplied.  The scheduling barriers keep the machine scheduler from
+    // sinking the loads next to their use to save registers, which is what it does otherwise -- and what removes the
+    // prefetch.
+    Ops o0, o1, o2;
+    auto stage = [&](int b, Ops& in_flight, const Ops& ready) {
+        fetch(b, in_flight);             // past the batch: clamped addresses, zero W
+        __builtin_amdgcn_sched_barrier(0);
+        compute(ready);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    fetch(0, o0);
+    fetch(GROUP, o1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int b0 = 0; b0 < nbins; b0 += 3 * GROUP) {
+        stage(b0 + 2 * GROUP, o2, o0);
+        if (b0 + GROUP >= nbins) break;
+        stage(b0 + 3 * GROUP, o0, o1);
+        if (b0 + 2 * GROUP >= nbins) break;
+        stage(b0 + 4 * GROUP, o1, o2);
     }
     // D layout: lane l, register r = [source 4*(l>>4) + r][frame l&15]
 #pragma unroll
-    for (int tl = 0; tl < kFrameTiles; ++tl) {
+    for (int tl = 0; tl < TILES; ++tl) {
         const int t = t0 + 16 * tl;
         if (t < T) {
 #pragma unroll
@@ -106,10 +145,21 @@ __global__ __launch_bounds__(kBlock) void power_mfma_kernel(const float2* __rest
 
 }  // namespace
 
-hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K) {
-    dim3 grid((F + kBinsPerBatch - 1) / kBinsPerBatch, (T + 16 * kWaves * kFrameTiles - 1) / (16 * kWaves * kFrameTiles));
-    power_mfma_kernel<<<grid, dim3(kBlock), 0, s>>>(X, What, Ppart, T, F, M, K);
+template <int TILES, int GROUP>
+static hipError_t launch_shape(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K) {
+    dim3 grid((F + kBinsPerBatch - 1) / kBinsPerBatch, (T + 16 * kWaves * TILES - 1) / (16 * kWaves * TILES));
+    if ((M & 3) == 0)
+        power_mfma_kernel<true, TILES, GROUP><<<grid, dim3(kBlock), 0, s>>>(X, What, Ppart, T, F, M, K);
+    else
+        power_mfma_kernel<false, TILES, GROUP><<<grid, dim3(kBlock), 0, s>>>(X, What, Ppart, T, F, M, K);
     return hipGetLastError();
+}
+
+hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K) {
+    // measured at 2048 x 4000 x 16 / 16 (tiles x bins per group): 4x1 252 us, 2x1 252, 2x2 267, 1x2 279, 1x4 306 -- the
+    // W operands come from L2 once per wave and bin, so more frames per wave is less W traffic (W-only 81 us at 1x4);
+    // X alone streams in 199 us, the MFMAs alone take 134 us
+    return launch_shape<4, 1>(s, X, What, Ppart, T, F, M, K);
 }
 
 }  // namespace oiva
