@@ -74,7 +74,10 @@ __global__ __launch_bounds__(64, 2) void cov_mfma16_kernel(const float2* __restr
 #pragma unroll
         for (int v = 0; v < WV; ++v) w[v] = row[v];
     };
-    // kDepth groups of x and kWDepth groups of weights are in flight per wave
+    // kDepth groups of x and kWDepth groups of weights are in flight per wave.  (The compiler's wait at the loop head is
+    // vmcnt(0), i.e. the effective distance is about one group; a variant with inline-assembly loads into kDepth slots
+    // and counted waits -- true distance 3 groups = 2 us -- measured the same 1.81-1.83 ms at 2048 x 4000 x 16 / 16, so
+    // latency is not what keeps the matrix pipe at 75 %, and the compiler-visible loads stay.)
     constexpr int kDepth = 4, kWDepth = 2;
     float2 xq[kDepth];
     float4 wq[kWDepth][WV];
