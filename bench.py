@@ -109,11 +109,12 @@ def _time_oracle(fs):
 
 
 def cpu_baseline():
-    """Reference-faithful NumPy restatement (oracle) on a bounded sample: 128 of the 2048 bins, all 4000
-    frames, 8 mics / 2 src; work is linear in bins, so it/s at 2048 bins = it/s on the sample * 128 / 2048.
+    """Reference-faithful NumPy restatement (oracle) on a bounded sample: 1024 of the 2048 bins, all 4000
+    frames, 8 mics / 2 src (about 15 s of CPU work); work is linear in bins, so it/s at 2048 bins = it/s on the sample
+    * 1024 / 2048.
     Timed with the default BLAS threading and, as the reference's own sweep pinned BLAS to one thread
     (overiva_sim.py:85-91), once more on a smaller sample with one thread."""
-    fs = 128
+    fs = 1024
     per_iter = _time_oracle(fs)
     threads = os.cpu_count()
     one = None
@@ -128,10 +129,12 @@ def cpu_baseline():
                "sample": f"{fs1} of {F} bins, one BLAS thread, {per1:.3f} s per iteration on the sample"}
     except Exception:
         pass
-    # `cores` = BLAS threads the run was ALLOWED to use; the batched (M x T)(T x M) products of overiva.py:179 do
-    # not thread in OpenBLAS (one thread gives the same rate, see single_thread), so it is effectively one core
-    return {"value": (1.0 / per_iter) * fs / F, "unit": "iterations/s", "cores": threads, "kind": "port",
-            "effective_cores": 1 if one and one["value"] > 0.8 * (1.0 / per_iter) * fs / F else threads,
+    # `cores` = the threads that actually did the work: the batched (M x T)(T x M) products of overiva.py:179 do not
+    # thread in OpenBLAS (one thread gives the same rate, see single_thread), so however many BLAS threads the run is
+    # allowed (blas_threads_allowed) it is one core
+    effective = 1 if one and one["value"] > 0.8 * (1.0 / per_iter) * fs / F else threads
+    return {"value": (1.0 / per_iter) * fs / F, "unit": "iterations/s", "cores": effective, "kind": "port",
+            "blas_threads_allowed": threads,
             "cpu": _cpu_model(), "host_cpus": os.cpu_count(), "single_thread": one,
             "sample": f"oracle.overiva_faithful (NumPy, complex64 in / float64 r like overiva.py) on {fs} of {F} bins x "
                       f"{T} frames x {M} mics / {K} src, iterations 2-5, scaled by {fs}/{F}; "

@@ -1,0 +1,47 @@
+#!/bin/bash
+# GPU box: everything profiles/rNN_* is made from.  Usage: bash tools/collect_profiles.sh   (writes gpurun_out/prof/)
+# Counters are collected in their own passes with --kernel-trace only (no --stats, no API traces), 4 counters per pass.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/prof
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="python3 $ROOT/bench.py"
+HEAD="--steps 6 --warmup 2 --no-cpu --no-other-mode --graph 0"
+
+# bench lines (the default run carries the CPU baseline)
+$B > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+$B --config cfg5 --no-cpu > "$OUT/bench_cfg5.json" 2> "$OUT/bench_cfg5.err"
+$B --force-sharded --no-cpu --no-other-mode > "$OUT/bench_sharded_1rank.json" 2> "$OUT/bench_sharded.err"
+
+# kernel-trace statistics of the bench command
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_headline" -o s -- $B --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_cfg5" -o s -- $B --config cfg5 --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
+
+# counters, headline shape, fast mode, eager launches
+i=0
+for c in "FETCH_SIZE" "WRITE_SIZE" \
+         "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" \
+         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" \
+         "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" \
+         "SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_headline/p$i" -o p -- $B $HEAD > /dev/null 2>&1
+done
+# HBM traffic of the precise mode (float64 covariance on the fp64 matrix cores, float64 per-bin algebra)
+i=0
+for c in "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_precise/p$i" -o p -- $B $HEAD --precision precise > /dev/null 2>&1
+done
+# matrix-core counters, cfg5
+i=0
+for c in "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+         "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_cfg5/p$i" -o p -- $B --config cfg5 $HEAD > /dev/null 2>&1
+done
+# keep what travels back small: drop the raw kernel traces of the --stats runs
+find "$OUT" -name "*_kernel_trace.csv" -path "*stats_*" -delete
+find "$OUT" -name "*_agent_info.csv" -delete
+du -sh "$OUT"
