@@ -130,6 +130,19 @@ int oiva_plan_update(oiva_plan *p, const void *parts_dev, int nparts);
  * row_pitch_bytes as in set_x_host (0 = dense).  Synchronous.
  */
 int oiva_plan_demix(oiva_plan *p, void *Y_host, long long row_pitch_bytes, int proj_back);
+/* Same, but Y stays on the device: *Y_dev is the plan's own (T, F, K) complex64 buffer, valid until the next demix of
+ * this plan or its destruction.  Hand it to oiva_plan_set_x_dev of another plan to chain two solves without a host
+ * round trip (the PCA front-end of auxiva_pca.py:79-87).  Synchronous. */
+int oiva_plan_demix_dev(oiva_plan *p, int proj_back, void **Y_dev);
+
+/*
+ * PCA front-end of auxiva_pca (auxiva_pca.py:71-81): W := the eigenvectors of the K largest eigenvalues of the input
+ * covariance, in ascending order of the eigenvalue (numpy.linalg.eigh's w[:, :, -K:]), from a Jacobi eigensolver on
+ * the device (float64, one wavefront per bin); the orthogonality constraint fills J as in oiva_plan_set_w.  A following
+ * demix gives new_X = X conj(w[:, :, -K:]).  The phase of each eigenvector is unspecified (as LAPACK's is a convention);
+ * results after projection back do not depend on it.  evals_host: NULL or (F, M) float64, all eigenvalues ascending.
+ */
+int oiva_plan_set_w_pca(oiva_plan *p, double *evals_host);
 /* W (F, M, K) complex64 (f64 = 0) or complex128 (f64 != 0) -- the view returned at overiva.py:201-202.
  * Synchronous.  Returns OIVA_ERR_NUMERIC if W holds a non-finite value (W is still copied out). */
 int oiva_plan_get_w(oiva_plan *p, void *W_host, int f64);

@@ -48,6 +48,8 @@ SIGNATURES = {
     "oiva_plan_power_buffer": [_vp, _i, C.POINTER(_vp), C.POINTER(_ll)],
     "oiva_plan_update": [_vp, _vp, _i],
     "oiva_plan_demix": [_vp, _vp, _ll, _i],
+    "oiva_plan_demix_dev": [_vp, _i, _vp],
+    "oiva_plan_set_w_pca": [_vp, _vp],
     "oiva_plan_get_w": [_vp, _vp, _i],
     "oiva_plan_sync": [_vp],
     "oiva_plan_iterate_timed": [_vp, _i, _fp, _fp],

@@ -1,9 +1,11 @@
 """Drop-in ``auxiva_pca()`` -- PCA to ``n_src`` channels followed by determined AuxIVA
 (reference ``auxiva_pca.py:30-92``).
 
-The covariance and the AuxIVA iterations run on the GPU; the Hermitian eigendecomposition of the
-(n_freq, n_chan, n_chan) covariance stays on the host (LAPACK, as in the reference,
-``auxiva_pca.py:75``) and so does the one-off projection onto the principal subspace.
+Everything runs on the GPU: the covariance, the Hermitian eigendecomposition (a Jacobi eigensolver, one wavefront per
+bin, ``csrc/kernels_evd.hip``; the reference calls LAPACK, ``auxiva_pca.py:75``), the projection onto the principal
+subspace -- whose result stays in device memory and is the input of the determined solve -- the AuxIVA iterations and
+the final demix + projection back.  The eigenvectors' phases are the eigensolver's, not LAPACK's; the result does not
+depend on them (a phase of a principal component becomes a phase of a demixed source, which projection back removes).
 """
 import numpy as np
 
@@ -34,10 +36,10 @@ def auxiva_pca(X, n_src=None, **kwargs):
         full.set_x(X)
         full.covariance()                                                     # auxiva_pca.py:71
         if n_src < n_chan:
-            _, vecs = np.linalg.eigh(full.get_cx(np.complex128))               # auxiva_pca.py:75 (host LAPACK)
-            P = np.ascontiguousarray(vecs[:, :, -n_src:])                     # (F, M, K) principal subspace
-            full.set_w(P)
-            new_X = full.demix(proj_back=False).astype(dtype, copy=False)     # x -> P^H x, auxiva_pca.py:79-81
+            full.set_w_pca()                                                  # auxiva_pca.py:75: eigh, w[:, :, -n_src:]
+            P = full.get_w(np.complex128)                                     # (F, M, K) principal subspace
+            new_X = full.demix_device(proj_back=False)                        # x -> P^H x, auxiva_pca.py:79-81
+            new_X.dtype = np.dtype(dtype)
         else:
             P = None
             new_X = X

@@ -193,6 +193,10 @@ hipError_t launch_ogive_switch(hipStream_t s, const OgiveState& st, int F, int M
 hipError_t launch_ogive_step(hipStream_t s, const OgiveState& st, const void* Vpart, bool vpart_f64, int nsplit, int T, int F,
                              int M, double mu, double tol);
 
+// W_hat = [eigenvectors of the K largest eigenvalues of Cx, ascending | [0; -I]]   (auxiva_pca.py:75-81); evals (F, M)
+// ascending or nullptr
+hipError_t launch_pca_subspace(hipStream_t s, const double* Cx, float2* What, double2* What64, double* evals, int F, int M, int K);
+
 // unpack packed Hermitian float64 [nmat][M*M] -> full complex nmat x (M,M): complex64, or complex128 when out_f64
 hipError_t launch_unpack_herm(hipStream_t s, const double* packed, void* full, bool out_f64, long long nmat, int M);
 

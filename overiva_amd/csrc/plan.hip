@@ -526,6 +526,41 @@ int oiva_plan_set_w(oiva_plan* p, const void* W0_host, int f64) {
     return OIVA_OK;
 }
 
+int oiva_plan_set_w_pca(oiva_plan* p, double* evals_host) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(p->have_cx, OIVA_ERR_STATE, "input covariance not computed (oiva_plan_covariance)");
+    DeviceGuard guard(p->device);
+    double* evals = evals_host ? p->scratch_p : nullptr;       // scratch_p holds at least K * F * M * M doubles
+    HIP_TRY(launch_pca_subspace(p->stream, p->Cx, p->What, p->What64, evals, p->F, p->M, p->K));
+    p->what64_valid = true;
+    p->wscale_pending = false;
+    p->have_w = true;
+    if (evals_host) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipMemcpy(evals_host, evals, (size_t)p->F * p->M * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (p->K < p->M) return stage_update(p, true);             // J from the orthogonality constraint
+    return OIVA_OK;
+}
+
+int oiva_plan_demix_dev(oiva_plan* p, int proj_back, void** Y_dev) {
+    int rc = check_ready(p);
+    if (rc) return rc;
+    NEED(Y_dev, OIVA_ERR_ARG, "null output");
+    DeviceGuard guard(p->device);
+    const size_t row = (size_t)p->F * p->K * sizeof(float2);
+    if (!p->Y) HIP_TRY(hipMalloc(&p->Y, row * p->T));
+    const float* sp = nullptr;
+    if (proj_back) {
+        HIP_TRY(launch_demix_stats(p->stream, p->X, p->What, p->Spart, p->T, p->F, p->M, p->K, p->stg));
+        sp = p->Spart;
+    }
+    HIP_TRY(launch_demix_write(p->stream, p->X, p->What, sp, p->stg.nsplit, p->Y, p->T, p->F, p->M, p->K));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    *Y_dev = p->Y;
+    return OIVA_OK;
+}
+
 int oiva_plan_iterate(oiva_plan* p, int n) {
     int rc = check_ready(p);
     if (rc) return rc;

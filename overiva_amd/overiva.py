@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 from . import sharded
-from .plan import Plan
+from .plan import DeviceX, Plan
 
 _device = None
 _precision = "precise"
@@ -114,7 +114,8 @@ def overiva(
     -------
     Y (nframes, nfrequencies, nsrc) in the dtype of X, or ``(Y, W)`` if ``return_filters``.
     """
-    X = np.asarray(X)
+    if not isinstance(X, DeviceX):     # (a DeviceX is a (T, F, M) complex64 tensor already on the GPU, see plan.py)
+        X = np.asarray(X)
     if X.ndim != 3:
         raise ValueError("X must have shape (n_frames, n_freq, n_chan)")
     dtype = _complex_dtype(X)
@@ -130,6 +131,8 @@ def overiva(
 
     precision = _precision
     group = sharded.active_group()
+    if group is not None and isinstance(X, DeviceX):
+        raise ValueError("a device-resident X cannot be sharded over ranks: pass the host array")
     if group is not None:
         solver = sharded.BinShardedSolver(n_frames, n_freq, n_chan, n_src, model, group=group[0], precision=precision)
     else:

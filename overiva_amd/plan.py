@@ -14,6 +14,18 @@ def _is_f64(a):
     raise TypeError(f"complex64 or complex128 expected, got {a.dtype}")
 
 
+class DeviceX:
+    """A dense (T, F, M) complex64 STFT tensor that already lives in the memory of this process's GPU: ``ptr`` is the
+    device address, ``owner`` whatever keeps it alive.  ``overiva()`` accepts it in place of a host array."""
+
+    def __init__(self, ptr, shape, owner=None, host_dtype=np.complex64):
+        self.ptr = int(ptr)
+        self.shape = tuple(int(v) for v in shape)
+        self.owner = owner
+        self.dtype = np.dtype(host_dtype)      # dtype results are returned in
+        self.ndim = 3
+
+
 class Plan:
     """Owns the device state of one AuxIVA/OverIVA problem (or one bin shard of it).
 
@@ -57,7 +69,12 @@ class Plan:
 
     # -- input --------------------------------------------------------------------------------
     def set_x(self, X, f0=0):
-        """X: (T, F_any, M) complex host array; uploads bins [f0, f0+F) as complex64."""
+        """X: (T, F_any, M) complex host array; uploads bins [f0, f0+F) as complex64.  A ``DeviceX`` of exactly this
+        plan's shape is borrowed instead."""
+        if isinstance(X, DeviceX):
+            if X.shape != (self.T, self.F, self.M) or f0:
+                raise ValueError(f"device X has shape {X.shape}, plan expects ({self.T}, {self.F}, {self.M})")
+            return self.set_x_device(X.ptr, X.owner)
         X = np.asarray(X)
         if X.ndim != 3 or X.shape[0] != self.T or X.shape[2] != self.M or X.shape[1] < f0 + self.F:
             raise ValueError(f"X has shape {X.shape}, plan expects ({self.T}, >={f0 + self.F}, {self.M})")
@@ -91,6 +108,14 @@ class Plan:
         dt = np.complex64 if W0.dtype == np.complex64 else np.complex128
         W0 = np.ascontiguousarray(np.broadcast_to(W0, (self.F, self.M, self.K)), dtype=dt)
         _lib.check(self.lib.oiva_plan_set_w(self.h, _lib.ptr(W0), _is_f64(W0)))
+
+    def set_w_pca(self, return_eigenvalues=False):
+        """W := eigenvectors of the K largest eigenvalues of the input covariance, ascending (``eigh``'s
+        ``w[:, :, -K:]``, auxiva_pca.py:75-81), from the Jacobi eigensolver on the device; optionally returns all
+        eigenvalues (F, M) ascending."""
+        ev = np.empty((self.F, self.M), np.float64) if return_eigenvalues else None
+        _lib.check(self.lib.oiva_plan_set_w_pca(self.h, _lib.ptr(ev) if ev is not None else None))
+        return ev
 
     # -- iteration ----------------------------------------------------------------------------
     def iterate(self, n=1):
@@ -145,6 +170,13 @@ class Plan:
         base = out.ctypes.data + f0 * self.K * 8
         _lib.check(self.lib.oiva_plan_demix(self.h, C.c_void_p(base), pitch, 1 if proj_back else 0))
         return out
+
+    def demix_device(self, proj_back=False):
+        """Y stays on the device: a ``DeviceX`` (T, F, K) that another plan can take as its input (``set_x``); valid
+        until this plan's next demix or its close()."""
+        dev = C.c_void_p()
+        _lib.check(self.lib.oiva_plan_demix_dev(self.h, 1 if proj_back else 0, C.byref(dev)))
+        return DeviceX(dev.value, (self.T, self.F, self.K), owner=self)
 
     def get_w(self, dtype=np.complex64):
         out = np.empty((self.F, self.M, self.K), dtype)

@@ -316,6 +316,42 @@ def test_auxiva_pca(oa, golden):
         oa.auxiva_pca(X.astype(np.complex128), n_src=K, n_iter=1)
 
 
+@pytest.mark.parametrize("shape", [(200, 9, 4, 2), (150, 6, 5, 2), (300, 7, 8, 3), (120, 3, 3, 1), (400, 5, 16, 4), (260, 4, 13, 6),
+                                   (90, 3, 2, 1), (250, 5, 8, 7)])
+def test_pca_subspace_on_device(oa, shape):
+    """the Jacobi eigensolver behind auxiva_pca (auxiva_pca.py:75-81) against numpy.linalg.eigh of the same covariance:
+    all eigenvalues, the projector onto the K principal eigenvectors, their order, orthonormality; then the projection
+    new_X = X conj(w[:, :, -K:]) up to the phase of each component, and that the device-resident new_X feeds a solve"""
+    T, F, M, K = shape
+    X = orc.synth_mixture(T, F, M, K, seed=sum(shape))
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision("precise")
+        p.set_x(X)
+        p.covariance()
+        Cx = p.get_cx(np.complex128)
+        ev = p.set_w_pca(return_eigenvalues=True)
+        P = p.get_w(np.complex128)
+        new_X = p.demix(proj_back=False)
+        dev = p.demix_device(proj_back=False)
+        assert dev.shape == (T, F, K)
+        Yd = oa.overiva(dev, n_iter=2, proj_back=False)
+        Yh = oa.overiva(new_X, n_iter=2, proj_back=False)
+    lam, vec = np.linalg.eigh(Cx)
+    assert np.max(np.abs(ev - lam)) <= 1e-12 * np.max(np.abs(lam))
+    Pr = vec[:, :, -K:]
+    eye = np.broadcast_to(np.eye(K), (F, K, K))
+    assert np.max(np.abs(np.conj(P.swapaxes(1, 2)) @ P - eye)) < 1e-12
+    gap = np.min(np.diff(lam, axis=1)) / np.max(lam)
+    tol = 1e-11 / max(gap, 1e-6)
+    # column by column: the same eigenvector up to a phase, in the same (ascending) order
+    c = np.abs(np.einsum("fmk,fmk->fk", np.conj(Pr), P))
+    assert np.max(np.abs(c - 1.0)) < tol, (np.max(np.abs(c - 1.0)), gap)
+    ref = np.einsum("tfm,fmk->tfk", X, np.conj(Pr)).astype(np.complex64)
+    phase = np.einsum("fmk,fmk->fk", np.conj(Pr), P)          # P = Pr * phase, so new_X = ref * conj(phase)
+    assert orc.rel_err(new_X, ref * np.conj(phase)[None]) < 1e-6
+    assert Yd.dtype == np.complex64 and np.array_equal(Yd, Yh)   # device hand-over == host round trip, bit for bit
+
+
 @pytest.mark.parametrize("shape", [(96, 5, 11, 3), (80, 3, 9, 9), (72, 6, 13, 1), (64, 4, 16, 5), (50, 7, 7, 7), (90, 19, 5, 2),
                                    (90, 21, 8, 3), (64, 9, 8, 4), (70, 5, 8, 5), (100, 12, 8, 8), (60, 7, 7, 4), (64, 5, 12, 12),
                                    (70, 4, 16, 16), (60, 3, 10, 10), (66, 2, 15, 15)])
