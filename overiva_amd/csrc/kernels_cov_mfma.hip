@@ -108,16 +108,25 @@ __global__ __launch_bounds__(64, 2) void cov_mfma16_kernel(const float2* __restr
                 const int t0 = t_begin + 4 * g;
                 const float live = (t0 + kf < t_end) ? xmask : 0.f;
                 const REAL xr = (REAL)(x.x * live), xi = (REAL)(x.y * live);
+                // With many sources: two rounds over them, so that the two MFMAs into are[kk] are never adjacent (a
+                // dependent MFMA issued right behind its producer waits for the result while the pipe idles): 1.82 ->
+                // 1.80 ms at 16 sources; with 2 sources the plain order measures 7 % faster (369 vs 395 us).
+                REAL ai[KW];
 #pragma unroll
                 for (int kk = 0; kk < KW; ++kk) {
-                    REAL ar = xr, ai = xi;
+                    REAL ar = xr;
+                    ai[kk] = xi;
                     if constexpr (!UNIT) {
                         ar = xr * (REAL)wl[kk];
-                        ai = xi * (REAL)wl[kk];
+                        ai[kk] = xi * (REAL)wl[kk];
                     }
                     are[kk] = Mfma<REAL>::run(ar, xr, are[kk]);
-                    are[kk] = Mfma<REAL>::run(ai, xi, are[kk]);
-                    air[kk] = Mfma<REAL>::run(ai, xr, air[kk]);
+                    if constexpr (KW < 8) are[kk] = Mfma<REAL>::run(ai[kk], xi, are[kk]);
+                    air[kk] = Mfma<REAL>::run(ai[kk], xr, air[kk]);
+                }
+                if constexpr (KW >= 8) {
+#pragma unroll
+                    for (int kk = 0; kk < KW; ++kk) are[kk] = Mfma<REAL>::run(ai[kk], xi, are[kk]);
                 }
             }
         }
