@@ -1,20 +1,14 @@
+#!/usr/bin/env python3
+"""GPU box: demix + power pass time against the number of frame splits:  T F M K splits..."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import overiva_amd as oa
-T, F, M, K = 4000, 2048, 8, 2
+import torch, overiva_amd as oa
+T, F, M, K = [int(a) for a in sys.argv[1:5]]
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 X = torch.view_as_complex(torch.randn((T, F, M, 2), generator=g, device="cuda"))
-torch.cuda.synchronize()
-p = oa.Plan(T, F, M, K, "laplace")
-p.set_x_device(X.data_ptr(), X)
-p.covariance(); p.set_w(None); p.iterate(2); p.sync()
-res = []
-for rnd in range(3):
-    for ns in (8, 12, 16, 24, 32, 48, 64):
-        p.set_pow_splits(ns)
-        res.append((ns, p.t_time_stage("demix_power", 10) * 1e3))
-import collections
-d = collections.defaultdict(list)
-for ns, t in res: d[ns].append(t)
-print("LDS pad", os.environ.get("OIVA_POW_LDS_PAD", "0"), {ns: [round(x) for x in v] for ns, v in d.items()})
+p = oa.Plan(T, F, M, K, "laplace"); p.set_x_device(X.data_ptr(), X); p.covariance(); p.set_w(None); p.iterate(2); p.sync()
+for ns in [int(a) for a in sys.argv[5:]]:
+    p.set_pow_splits(ns)
+    p.iterate(1); p.sync()
+    ts = [p.t_time_stage('demix_power', 20) * 1e3 for _ in range(3)]
+    print(f"pow splits {ns:3d}: power {min(ts):6.1f} us (3 x 20 launches: {' '.join(f'{t:.1f}' for t in ts)})", flush=True)
