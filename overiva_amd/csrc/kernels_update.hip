@@ -761,7 +761,7 @@ hipError_t launch_update(hipStream_t s, const UpdateArgs& a) {
         if (a.M <= 4) return launch_sq<4>(s, a);
         if (a.M <= 8) return launch_sq<8>(s, a);
     }
-    if (a.layout == 0 && a.M > 8 && a.M <= 16) return launch_update_lds16(s, a);   // one workgroup per bin
+    if (a.layout == 0 && a.M > 8 && a.M <= 16) return launch_update_wave16(s, a);   // one wavefront per bin
     if (a.M <= 2) return launch_sg<2>(s, a);
     if (a.M <= 4) return launch_sg<4>(s, a);
     if (a.M <= 8) return launch_sg<8>(s, a);

@@ -1,11 +1,8 @@
 // Per-bin sequential algebra for 9..16 channels                            reference overiva.py:176-190
 //
 // Same mathematics as update_sq_kernel (kernels_update.hip) -- per source: A = W_hat^H V_s, Gauss-Jordan with
-// partial pivoting for A w = e_s, w /= sqrt(w^H V w), J from the orthogonality constraint -- with ONE WORKGROUP
-// per bin: 256 lanes = the 16 x 16 matrix, lane (i, j) = tid / 16, tid % 16 holds element [i][j].  A 16 x 16
-// matrix spans four wavefronts, so rows / columns / pivots travel through LDS (two barriers per elimination
-// step) instead of lane permutes.  Every lane does O(1) arithmetic per step; 2048 bins = 2048 workgroups run
-// concurrently.  (The row-per-lane variant needs ~1 ms for 16 sources x 16 channels; this one a few tens of us.)
+// partial pivoting for A w = e_s, w /= sqrt(w^H V w), J from the orthogonality constraint -- with ONE WAVEFRONT per
+// bin and four matrix elements per lane (a 16 x 16 matrix has 256).
 #include "oiva_device.h"
 
 #include <type_traits>
@@ -33,83 +30,6 @@ __device__ __forceinline__ C2<R> cinv(C2<R> a) {
     return {a.re * d, -a.im * d};
 }
 
-template <typename R>
-struct Lds16 {
-    C2<R> mA[N][N + 1];   // left operand of a product (W_hat^H)
-    C2<R> mB[N][N + 1];   // right operand (V or Cx)
-    C2<R> row[N];         // pivot row
-    C2<R> col[N];         // pivot column
-    C2<R> q[N];           // solution / per-column scratch
-    C2<R> rhs_p;          // right-hand side of the pivot row
-    float mag[N];
-    int pivrow[N];        // pivrow[c] = row that pivoted column c
-    double red[kWaves];
-};
-
-// out[i][j] = sum_m L[i][m] * Rm[m][j] over m < M, operands distributed one element per lane
-template <typename R>
-__device__ __forceinline__ C2<R> matmul(Lds16<R>& s, C2<R> L, C2<R> Rm, int i, int j, int M) {
-    __syncthreads();
-    s.mA[i][j] = L;
-    s.mB[i][j] = Rm;
-    __syncthreads();
-    C2<R> acc = {R(0), R(0)};
-    for (int m = 0; m < M; ++m) {
-        const C2<R> a = s.mA[i][m], b = s.mB[m][j];
-        acc.re += a.re * b.re - a.im * b.im;
-        acc.im += a.re * b.im + a.im * b.re;
-    }
-    return acc;
-}
-
-// Gauss-Jordan with partial pivoting over columns 0..npiv-1.  rhs is a per-row scalar replicated along the
-// row; rows with used == true are never chosen.  Afterwards s.pivrow[c] = pivot row of column c; for a pivot
-// row, mycol = the column it pivoted and piv its pivot element.
-template <typename R>
-__device__ __forceinline__ void gauss_jordan(Lds16<R>& s, C2<R>& A, C2<R>& rhs, int npiv, bool used, int& mycol,
-                                             C2<R>& piv, int i, int j) {
-    for (int c = 0; c < npiv; ++c) {
-        if (j == c) s.mag[i] = used ? -1.f : (float)(A.re * A.re + A.im * A.im);
-        __syncthreads();
-        int p = 0;
-        float best = s.mag[0];
-#pragma unroll
-        for (int r = 1; r < N; ++r) {
-            const float v = s.mag[r];
-            if (v > best) {
-                best = v;
-                p = r;
-            }
-        }
-        if (i == p) s.row[j] = A;
-        if (j == c) s.col[i] = A;
-        if (i == p && j == 0) {
-            s.rhs_p = rhs;
-            s.pivrow[c] = p;
-        }
-        __syncthreads();
-        const C2<R> apc = s.col[p], aic = s.col[i], apj = s.row[j], bp = s.rhs_p;
-        if (i == p) {
-            used = true;
-            mycol = c;
-            piv = apc;
-        } else {
-            const C2<R> fct = cmul(aic, cinv(apc));
-            const C2<R> d1 = cmul(fct, apj), d2 = cmul(fct, bp);
-            A.re -= d1.re;
-            A.im -= d1.im;
-            rhs.re -= d2.re;
-            rhs.im -= d2.im;
-            if (j == c) A = {R(0), R(0)};
-        }
-    }
-}
-
-template <typename R>
-__device__ __forceinline__ R block_sum16(Lds16<R>& s, R v) {
-    return (R)block_sum((double)v, s.red);
-}
-
 __device__ __forceinline__ void herm_off(int M, int i, int j, int& off, float& sgn) {
     if (i == j) {
         off = i;
@@ -123,125 +43,14 @@ __device__ __forceinline__ void herm_off(int M, int i, int j, int& off, float& s
     }
 }
 
-template <typename R>
-__global__ __launch_bounds__(kBlock) void update_lds16_kernel(UpdateArgs a) {
-    __shared__ Lds16<R> s;
-    const int tid = threadIdx.x;
-    const int i = tid >> 4, j = tid & 15;
-    const int f = blockIdx.x;
-    const int M = a.M, K = a.K;
-    const int NA = M * M;
-    const bool in = i < M && j < M;
-    const C2<R> zero = {R(0), R(0)};
-    const C2<R> eye = {R(i == j ? 1 : 0), R(0)};
-
-    // B[i][j] = (W_hat^H)[i][j] = conj(W_hat[j][i]); identity outside M x M
-    C2<R> B = eye;
-    if (in) {
-        R vr, vi;
-        load_what<R>(a, ((size_t)f * M + j) * M + i, vr, vi);
-        B = {vr, -vi};
-    }
-    if (a.wscale != nullptr && i < K) {   // overiva.py:163 / :167
-        const R sc = R(1) / R(a.wscale[i]);
-        B.re *= sc;
-        B.im *= sc;
-    }
-    int off = 0;
-    float sgn = 0.f;
-    if (in) herm_off(M, i, j, off, sgn);
-    C2<R> C = zero;
-    if (in) {
-        const double* p = a.Cx + (size_t)f * NA + off;
-        C.re = R(p[0]);
-        if (sgn != 0.f) C.im = R(sgn * p[1]);
-    }
-    C2<R> Tm = zero;                      // rows < K: W^H Cx
-    if (K < M) Tm = matmul(s, B, C, i, j, M);
-
-    const int nsrc = a.init_only ? 0 : K;
-    const R invT = R(1) / R(a.T);
-    // V_s[i][j]: fixed-order fp64 sum of the frame-split partials; the loads of source s+1 are issued before
-    // source s is solved
-    auto load_v = [&](int src) {
-        C2<R> V = zero;
-        if (in) {
-            double sr, si;
-            sum_vpart(a.Vpart, a.vpart_f64, ((size_t)f * K + src) * NA + off, (size_t)a.F * K * NA, a.nsplit, sgn != 0.f, sr, si);
-            V.re = R(sr) * invT;
-            V.im = R(si) * R(sgn) * invT;
-        }
-        return V;
-    };
-    C2<R> Vnext = zero;
-    if (nsrc > 0) Vnext = load_v(0);
-    for (int src = 0; src <= nsrc; ++src) {
-        const bool solve = src < nsrc;
-        if (!solve && !a.init_only) break;
-        C2<R> wi = zero, wj = zero;
-        if (solve) {
-            const C2<R> V = Vnext;
-            if (src + 1 < nsrc) Vnext = load_v(src + 1);
-            C2<R> A = matmul(s, B, V, i, j, M);   // W_hat^H V
-            if (!in) A = eye;
-            C2<R> rhs = {R(i == src ? 1 : 0), R(0)};
-            int mycol = i;
-            C2<R> piv = {R(1), R(0)};
-            gauss_jordan(s, A, rhs, N, false, mycol, piv, i, j);
-            // w[c] = rhs / pivot on the row that pivoted column c
-            __syncthreads();
-            if (j == 0) s.q[mycol] = cmul(rhs, cinv(piv));
-            __syncthreads();
-            wi = s.q[i];
-            wj = s.q[j];
-            // d = w^H V w  (real, positive)
-            const C2<R> vw = cmul(V, wj);
-            const R d = block_sum16(s, wi.re * vw.re + wi.im * vw.im);
-            const R sc = R(1) / sqrt(d);
-            wi.re *= sc;
-            wi.im *= sc;
-            wj.re *= sc;
-            wj.im *= sc;
-            if (i == src) B = cconj(wj);
-        }
-        if (K < M) {
-            if (solve) {
-                // row src of W^H Cx = sum_m conj(w_m) Cx[m][:]  (column sums over i)
-                __syncthreads();
-                s.mA[i][j] = cmul(cconj(wi), C);
-                __syncthreads();
-                C2<R> t = zero;
-                for (int m = 0; m < M; ++m) {
-                    t.re += s.mA[m][j].re;
-                    t.im += s.mA[m][j].im;
-                }
-                if (i == src) Tm = t;
-            }
-            C2<R> G = (i < K) ? Tm : eye;
-            C2<R> dummy = zero;
-            int mycol = i;
-            C2<R> piv = {R(1), R(0)};
-            gauss_jordan(s, G, dummy, K, i >= K, mycol, piv, i, j);
-            // J[m][j-K] = G[pivrow[m]][j] / pivot: the pivot rows publish their normalised rows at index m
-            __syncthreads();
-            if (i < K) s.mB[mycol][j] = cmul(G, cinv(piv));
-            __syncthreads();
-            // W_hat[m][i] = J[m][i-K]  ->  (W_hat^H)[i][m] = conj, for i >= K, m = j < K
-            if (i >= K && i < M && j < K) B = cconj(s.mB[j][i]);
-        }
-    }
-    if (in) store_what<R>(a, ((size_t)f * M + j) * M + i, B.re, -B.im);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Determined case K == M (AuxIVA, overiva.py:176-181 only): ONE WAVEFRONT per bin.
 // Lane l = (i, q) = (l >> 2, l & 3) owns row i of the 16 x 16 matrices, columns q, q + 4, q + 8, q + 12 (element e is
 // column 4e + q).  A row's 16 entries sit in one quad, so a column entry reaches its row by a quad-permute DPP; the
 // pivot is an arg-max over a packed (magnitude, row) key by two row rotations and two lane exchanges; the pivot row is
 // published through LDS (same-address reads broadcast).  Nothing crosses a wavefront: no barrier waits on another wave,
 // and Gauss-Jordan skips the columns that are already eliminated (known at compile time in the unrolled loop).
-// Instruction count per bin is about a fifth of the workgroup-per-bin form above.
+// (Round 1 used a workgroup of 256 lanes per bin, one element per lane, with rows / columns / pivots through LDS and two
+// barriers per elimination step: 516 us at 2048 x 16 / 16 against 142 us here, 366 -> 113 us at 8 sources, 97 -> 39 us at 2.)
+
 // entry of quad lane QL to the whole quad
 template <int QL, typename R>
 __device__ __forceinline__ C2<R> quad_bcast(C2<R> v) {
@@ -292,14 +101,17 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename R, typename VT>
-__global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
+template <typename R, typename VT, bool OVER>   // OVER: K < M, background rows and the orthogonality constraint
+__global__ __launch_bounds__(64) void update_wave16_kernel(UpdateArgs a) {
     __shared__ LdsDet<R> s;
     const int lane = threadIdx.x, i = lane >> 2, q = lane & 3;
-    const int f = blockIdx.x, M = a.M, NA = M * M;
+    const int f = blockIdx.x, M = a.M, K = a.K, NA = M * M;
     const C2<R> zero = {R(0), R(0)};
-    // B = W_hat^H, identity outside M x M
-    C2<R> B[4];
+    // (a run-time test in the K < M instantiation: with the branch known taken the compiler's schedule needs 290-450
+    // registers and spills; kept uniform and 'unknown' it needs 173-268)
+    const bool over = OVER && K < M;
+    // B = W_hat^H, identity outside M x M; C = Cx (only needed for the orthogonality constraint, K < M)
+    C2<R> B[4], C[4];
     int off[4];
     float sgn[4];
     bool in[4];
@@ -308,6 +120,7 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
         const int c = 4 * e + q;
         in[e] = i < M && c < M;
         B[e] = {R(i == c ? 1 : 0), R(0)};
+        C[e] = zero;
         off[e] = 0;
         sgn[e] = 0.f;
         if (in[e]) {
@@ -315,13 +128,99 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
             load_what<R>(a, ((size_t)f * M + c) * M + i, vr, vi);
             B[e] = {vr, -vi};
             herm_off(M, i, c, off[e], sgn[e]);
+            if (over) {
+                const double* pc = a.Cx + (size_t)f * NA + off[e];
+                C[e].re = R(pc[0]);
+                if (sgn[e] != 0.f) C[e].im = R(sgn[e] * pc[1]);
+            }
         }
     }
-    if (a.wscale != nullptr && i < M) {                   // overiva.py:163 / :167
+    if (a.wscale != nullptr && i < K) {                   // overiva.py:163 / :167
         const R sc = R(1) / R(a.wscale[i]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) B[e] = {B[e].re * sc, B[e].im * sc};
     }
+    // out[i][4e + q] = sum_m B[i][m] S[m][4e + q] with S in LDS (s.V, a lane's four columns contiguous)
+    auto times_lds = [&](C2<R> (&out)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = zero;
+#pragma unroll
+        for (int me = 0; me < 4; ++me) {
+            auto term = [&](C2<R> b, int m) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const C2<R> v = s.V[m][q * 4 + e];
+                    out[e].re += b.re * v.re - b.im * v.im;
+                    out[e].im += b.re * v.im + b.im * v.re;
+                }
+            };
+            term(quad_bcast<0>(B[me]), 4 * me + 0);
+            term(quad_bcast<1>(B[me]), 4 * me + 1);
+            term(quad_bcast<2>(B[me]), 4 * me + 2);
+            term(quad_bcast<3>(B[me]), 4 * me + 3);
+        }
+    };
+    auto to_lds = [&](const C2<R> (&m)[4]) {
+        wave_lds_sync();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s.V[i][q * 4 + e] = m[e];
+        wave_lds_sync();
+    };
+    C2<R> Tm[4] = {zero, zero, zero, zero};               // rows < K: W^H Cx
+    if (over) {
+        to_lds(C);
+        times_lds(Tm);
+    }
+    // one Gauss-Jordan step with partial pivoting on column c of [A | rhs]; rows with `used` are never chosen
+    auto step = [&](auto cc, C2<R> (&A)[4], C2<R>& rhs, bool& used, C2<R>& piv, int& mycol) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int ce = c >> 2, cq = c & 3;
+        constexpr int e0 = (c + 1) >> 2;                   // elements below e0 hold only eliminated columns
+        const C2<R> aic = quad_bcast<cq>(A[ce]);
+        const float mag = (float)(aic.re * aic.re + aic.im * aic.im);
+        unsigned key = used ? 0u : ((__float_as_uint(mag) & ~31u) | 16u | (unsigned)(15 - i));
+        unsigned o;
+        o = dpp<kDppRor4>(key); key = o > key ? o : key;
+        o = dpp<kDppRor8>(key); key = o > key ? o : key;
+        key = swapmax32(swapmax16(key));
+        const int p = 15 - (int)(__builtin_amdgcn_readfirstlane((int)key) & 15);
+        wave_lds_sync();
+        if (i == p) {
+#pragma unroll
+            for (int e = e0; e < 4; ++e) s.prow[q][e] = A[e];
+            if (q == 0) {
+                s.ppiv = aic;
+                s.prhs = rhs;
+            }
+        }
+        wave_lds_sync();
+        const C2<R> apc = s.ppiv, bp = s.prhs;
+        const bool mine = i == p;
+        used = used || mine;
+        mycol = mine ? c : mycol;
+        piv.re = mine ? apc.re : piv.re;                   // (component-wise: a select of the pair goes through scratch)
+        piv.im = mine ? apc.im : piv.im;
+        C2<R> fct = cmul(aic, cinv_fast(apc));
+        fct.re = mine ? R(0) : fct.re;                     // the pivot row eliminates with factor 0
+        fct.im = mine ? R(0) : fct.im;
+#pragma unroll
+        for (int e = e0; e < 4; ++e) {
+            const C2<R> r = s.prow[q][e];
+            A[e].re -= fct.re * r.re - fct.im * r.im;
+            A[e].im -= fct.re * r.im + fct.im * r.re;
+        }
+        rhs.re -= fct.re * bp.re - fct.im * bp.im;
+        rhs.im -= fct.re * bp.im + fct.im * bp.re;
+    };
+    // columns 0 .. npiv-1 (npiv uniform)
+    auto gauss_jordan = [&](int npiv, C2<R> (&A)[4], C2<R>& rhs, bool& used, C2<R>& piv, int& mycol) {
+#define OIVA_GJ_STEP(c) \
+    if (c < npiv) step(std::integral_constant<int, c>{}, A, rhs, used, piv, mycol);
+        OIVA_GJ_STEP(0) OIVA_GJ_STEP(1) OIVA_GJ_STEP(2) OIVA_GJ_STEP(3) OIVA_GJ_STEP(4) OIVA_GJ_STEP(5) OIVA_GJ_STEP(6)
+        OIVA_GJ_STEP(7) OIVA_GJ_STEP(8) OIVA_GJ_STEP(9) OIVA_GJ_STEP(10) OIVA_GJ_STEP(11) OIVA_GJ_STEP(12)
+        OIVA_GJ_STEP(13) OIVA_GJ_STEP(14) OIVA_GJ_STEP(15)
+#undef OIVA_GJ_STEP
+    };
     const R invT = R(1) / R(a.T);
     // V_s arrives as the packed Hermitian block of every frame split ([split][bin][source][M * M]): lane l fetches
     // values 4l .. 4l + 3 of each block (16-byte loads when M is even), the splits are added in order in float64, the
@@ -329,10 +228,10 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
     // is solved.
     constexpr int kAhead = 8;                                 // splits held in registers across a solve
     const VT* vbase = static_cast<const VT*>(a.Vpart);
-    const size_t vstride = (size_t)a.F * M * NA;
+    const size_t vstride = (size_t)a.F * K * NA;
     const int nahead = a.nsplit < kAhead ? a.nsplit : kAhead;
     auto fetch = [&](int src, int sp, VT (&raw)[4]) {
-        const VT* p = vbase + (size_t)sp * vstride + ((size_t)f * M + src) * NA + lane * 4;
+        const VT* p = vbase + (size_t)sp * vstride + ((size_t)f * K + src) * NA + lane * 4;
         if ((M & 1) == 0) {                                   // block start and length are multiples of 4 values
             if (lane * 4 < NA) {
                 if constexpr (sizeof(VT) == 4) {
@@ -355,139 +254,112 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
         for (int sp = 0; sp < kAhead; ++sp)
             if (sp < nahead) fetch(src, sp, raw[sp]);
     };
-    fetch_ahead(0);
-    for (int src = 0; src < M; ++src) {
-        double acc[4] = {0., 0., 0., 0.};
+    const int nsrc = a.init_only ? 0 : K;
+    if (nsrc > 0) fetch_ahead(0);
+    for (int src = 0; src <= nsrc; ++src) {
+        const bool solve = src < nsrc;
+        if (!solve && !a.init_only) break;
+        C2<R> wi = zero;
+        if (solve) {
+            double acc[4] = {0., 0., 0., 0.};
 #pragma unroll
-        for (int sp = 0; sp < kAhead; ++sp)
-            if (sp < nahead) {
+            for (int sp = 0; sp < kAhead; ++sp)
+                if (sp < nahead) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] += (double)raw[sp][r];
+                    for (int r = 0; r < 4; ++r) acc[r] += (double)raw[sp][r];
+                }
+            for (int sp = kAhead; sp < a.nsplit; ++sp) {       // very long frame axes only
+                VT more[4] = {VT(0), VT(0), VT(0), VT(0)};
+                fetch(src, sp, more);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] += (double)more[r];
             }
-        for (int sp = kAhead; sp < a.nsplit; ++sp) {           // very long frame axes only
-            VT more[4] = {VT(0), VT(0), VT(0), VT(0)};
-            fetch(src, sp, more);
+            if (src + 1 < nsrc) fetch_ahead(src + 1);
+            wave_lds_sync();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += (double)more[r];
-        }
-        if (src + 1 < M) fetch_ahead(src + 1);
-        wave_lds_sync();
+            for (int r = 0; r < 4; ++r) s.pk[lane * 4 + r] = R(acc[r]);
+            wave_lds_sync();
+            C2<R> V[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s.pk[lane * 4 + r] = R(acc[r]);
-        wave_lds_sync();
-        C2<R> V[4];
+            for (int e = 0; e < 4; ++e) {
+                V[e] = zero;
+                if (in[e]) {
+                    V[e].re = s.pk[off[e]] * invT;
+                    if (sgn[e] != 0.f) V[e].im = s.pk[off[e] + 1] * R(sgn[e]) * invT;
+                }
+            }
+            to_lds(V);
+            C2<R> A[4];
+            times_lds(A);                                      // A = W_hat^H V
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            V[e] = zero;
-            if (in[e]) {
-                V[e].re = s.pk[off[e]] * invT;
-                if (sgn[e] != 0.f) V[e].im = s.pk[off[e] + 1] * R(sgn[e]) * invT;
+            for (int e = 0; e < 4; ++e)
+                if (!in[e]) A[e] = {R(i == 4 * e + q ? 1 : 0), R(0)};
+            // Gauss-Jordan with partial pivoting on [A | e_src]
+            C2<R> rhs = {R(i == src ? 1 : 0), R(0)};
+            bool used = false;
+            C2<R> piv = {R(1), R(0)};
+            int mycol = i;
+            gauss_jordan(N, A, rhs, used, piv, mycol);
+            // w[c] = rhs / pivot on the row that pivoted column c
+            wave_lds_sync();
+            if (q == 0) s.w[mycol] = cmul(rhs, cinv(piv));
+            wave_lds_sync();
+            wi = s.w[i];
+            C2<R> wc[4];
+            // d = w^H V w (real, positive): row i of V w from this lane's four columns, then over the quad and the rows
+            R tr = R(0), ti = R(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wc[e] = s.w[4 * e + q];
+                tr += V[e].re * wc[e].re - V[e].im * wc[e].im;
+                ti += V[e].re * wc[e].im + V[e].im * wc[e].re;
+            }
+            tr = quad_sum(tr);
+            ti = quad_sum(ti);
+            const R d = wave_sum16(wi.re * tr + wi.im * ti);
+            const R sc = R(1) / sqrt(d);
+            wi = {wi.re * sc, wi.im * sc};
+            if (i == src) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) B[e] = {wc[e].re * sc, -wc[e].im * sc};
             }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s.V[i][q * 4 + e] = V[e];
-        wave_lds_sync();
-        // A = W_hat^H V: A[i][4e + q] = sum_m B[i][m] V[m][4e + q]
-        C2<R> A[4] = {zero, zero, zero, zero};
-#pragma unroll
-        for (int me = 0; me < 4; ++me) {
-            auto term = [&](C2<R> b, int m) {
+        if (over) {                                            // orthogonality constraint, overiva.py:189-190 -> :96-98
+            if (solve) {
+                // row src of W^H Cx = sum_m conj(w_m) Cx[m][:]: column sums over the 16 rows (lanes of equal q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const C2<R> v = s.V[m][q * 4 + e];
-                    A[e].re += b.re * v.re - b.im * v.im;
-                    A[e].im += b.re * v.im + b.im * v.re;
+                    const C2<R> x = cmul(cconj(wi), C[e]);
+                    const R tre = wave_sum16(x.re), tim = wave_sum16(x.im);
+                    if (i == src) Tm[e] = {tre, tim};
                 }
-            };
-            term(quad_bcast<0>(B[me]), 4 * me + 0);
-            term(quad_bcast<1>(B[me]), 4 * me + 1);
-            term(quad_bcast<2>(B[me]), 4 * me + 2);
-            term(quad_bcast<3>(B[me]), 4 * me + 3);
-        }
+            }
+            // J = (W^H Cx)[:, :K]^-1 (W^H Cx)[:, K:]: eliminate the first K columns on the first K rows
+            C2<R> G[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (!in[e]) A[e] = {R(i == 4 * e + q ? 1 : 0), R(0)};
-        // Gauss-Jordan with partial pivoting on [A | e_src]
-        C2<R> rhs = {R(i == src ? 1 : 0), R(0)};
-        bool used = false;
-        C2<R> piv = {R(1), R(0)};
-        int mycol = i;
-        auto step = [&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int ce = c >> 2, cq = c & 3;
-            constexpr int e0 = (c + 1) >> 2;               // elements below e0 hold only eliminated columns
-            const C2<R> aic = quad_bcast<cq>(A[ce]);
-            const float mag = (float)(aic.re * aic.re + aic.im * aic.im);
-            unsigned key = used ? 0u : ((__float_as_uint(mag) & ~31u) | 16u | (unsigned)(15 - i));
-            unsigned o;
-            o = dpp<kDppRor4>(key); key = o > key ? o : key;
-            o = dpp<kDppRor8>(key); key = o > key ? o : key;
-            key = swapmax32(swapmax16(key));
-            const int p = 15 - (int)(__builtin_amdgcn_readfirstlane((int)key) & 15);
+            for (int e = 0; e < 4; ++e) G[e] = i < K ? Tm[e] : C2<R>{R(i == 4 * e + q ? 1 : 0), R(0)};
+            C2<R> dummy = zero;
+            bool used = i >= K;
+            C2<R> piv = {R(1), R(0)};
+            int mycol = i;
+            gauss_jordan(K, G, dummy, used, piv, mycol);
+            // J[m][j] = G[row that pivoted column m][j] / pivot: the pivot rows publish their normalised rows at index m
             wave_lds_sync();
-            if (i == p) {
+            if (i < K) {
+                const C2<R> ip = cinv(piv);
 #pragma unroll
-                for (int e = e0; e < 4; ++e) s.prow[q][e] = A[e];
-                if (q == 0) {
-                    s.ppiv = aic;
-                    s.prhs = rhs;
+                for (int e = 0; e < 4; ++e) s.V[mycol][q * 4 + e] = cmul(G[e], ip);
+            }
+            wave_lds_sync();
+            // W_hat[m][i] = J[m][i - K]  ->  (W_hat^H)[i][m] = conj, for rows i >= K and columns m < K
+            if (i >= K && i < M) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = 4 * e + q;
+                    if (m < K) B[e] = cconj(s.V[m][(i & 3) * 4 + (i >> 2)]);
                 }
             }
             wave_lds_sync();
-            const C2<R> apc = s.ppiv, bp = s.prhs;
-            const bool mine = i == p;
-            used = used || mine;
-            mycol = mine ? c : mycol;
-            piv.re = mine ? apc.re : piv.re;                   // (component-wise: a select of the pair goes through scratch)
-            piv.im = mine ? apc.im : piv.im;
-            C2<R> fct = cmul(aic, cinv_fast(apc));
-            fct.re = mine ? R(0) : fct.re;                     // the pivot row eliminates with factor 0
-            fct.im = mine ? R(0) : fct.im;
-#pragma unroll
-            for (int e = e0; e < 4; ++e) {
-                const C2<R> r = s.prow[q][e];
-                A[e].re -= fct.re * r.re - fct.im * r.im;
-                A[e].im -= fct.re * r.im + fct.im * r.re;
-            }
-            rhs.re -= fct.re * bp.re - fct.im * bp.im;
-            rhs.im -= fct.re * bp.im + fct.im * bp.re;
-        };
-        step(std::integral_constant<int, 0>{});
-        step(std::integral_constant<int, 1>{});
-        step(std::integral_constant<int, 2>{});
-        step(std::integral_constant<int, 3>{});
-        step(std::integral_constant<int, 4>{});
-        step(std::integral_constant<int, 5>{});
-        step(std::integral_constant<int, 6>{});
-        step(std::integral_constant<int, 7>{});
-        step(std::integral_constant<int, 8>{});
-        step(std::integral_constant<int, 9>{});
-        step(std::integral_constant<int, 10>{});
-        step(std::integral_constant<int, 11>{});
-        step(std::integral_constant<int, 12>{});
-        step(std::integral_constant<int, 13>{});
-        step(std::integral_constant<int, 14>{});
-        step(std::integral_constant<int, 15>{});
-        // w[c] = rhs / pivot on the row that pivoted column c
-        wave_lds_sync();
-        if (q == 0) s.w[mycol] = cmul(rhs, cinv(piv));
-        wave_lds_sync();
-        C2<R> wi = s.w[i], wc[4];
-        // d = w^H V w (real, positive): row i of V w from this lane's four columns, then over the quad and the rows
-        R tr = R(0), ti = R(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            wc[e] = s.w[4 * e + q];
-            tr += V[e].re * wc[e].re - V[e].im * wc[e].im;
-            ti += V[e].re * wc[e].im + V[e].im * wc[e].re;
-        }
-        tr = quad_sum(tr);
-        ti = quad_sum(ti);
-        const R d = wave_sum16(wi.re * tr + wi.im * ti);
-        const R sc = R(1) / sqrt(d);
-        if (i == src) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) B[e] = {wc[e].re * sc, -wc[e].im * sc};
         }
     }
 #pragma unroll
@@ -497,23 +369,19 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
 
 }  // namespace
 
-hipError_t launch_update_lds16(hipStream_t s, const UpdateArgs& a) {
+hipError_t launch_update_wave16(hipStream_t s, const UpdateArgs& a) {
     dim3 grid(a.F);
-    if (a.K == a.M && !a.init_only) {                     // determined: one wavefront per bin
-        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(64), 0, s, a); };
-        if (a.use_double) {
-            if (a.vpart_f64) go(update_det16_kernel<double, double>);
-            else go(update_det16_kernel<double, float>);
-        } else {
-            if (a.vpart_f64) go(update_det16_kernel<float, double>);
-            else go(update_det16_kernel<float, float>);
-        }
-        return hipGetLastError();
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(64), 0, s, a); };
+    const bool over = a.K < a.M;
+#define OIVA_GO(RR, VV)                                         \
+    if (over) go(update_wave16_kernel<RR, VV, true>);           \
+    else go(update_wave16_kernel<RR, VV, false>);
+    if (a.use_double) {
+        if (a.vpart_f64) { OIVA_GO(double, double) } else { OIVA_GO(double, float) }
+    } else {
+        if (a.vpart_f64) { OIVA_GO(float, double) } else { OIVA_GO(float, float) }
     }
-    if (a.use_double)
-        hipLaunchKernelGGL((update_lds16_kernel<double>), grid, dim3(kBlock), 0, s, a);
-    else
-        hipLaunchKernelGGL((update_lds16_kernel<float>), grid, dim3(kBlock), 0, s, a);
+#undef OIVA_GO
     return hipGetLastError();
 }
 

@@ -162,7 +162,7 @@ __device__ __forceinline__ void sum_vpart(const void* base, int f64, size_t idx,
     if (!pair) si = 0.;
 }
 hipError_t launch_update(hipStream_t s, const UpdateArgs& a);
-hipError_t launch_update_lds16(hipStream_t s, const UpdateArgs& a);   // 9..16 channels, one workgroup per bin
+hipError_t launch_update_wave16(hipStream_t s, const UpdateArgs& a);   // 9..16 channels, one wavefront per bin
 
 // Epilogue, overiva.py:192-199.
 //   stats: per-bin sums for projection back: [nsplit][F][K][3] = (Re num, Im num, den)
