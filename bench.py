@@ -310,6 +310,10 @@ def run_sharded(args):
         stream.synchronize()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # roofline of the dominant kernel on this rank's shard: the covariance kernel alone, HIP events on the plan's
+        # stream (same definition as the single-GPU line, with this rank's number of bins)
+        cov_ms = eng.plan.t_time_stage("weighted_cov", 20)
+        stream.synchronize()
     dist.barrier()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -320,6 +324,20 @@ def run_sharded(args):
     dist.all_gather_object(gathered, {"rank": rank, "bins": [f0, f1], **breakdown})
     out = result_line(args, world, float(tmax.item()))
     out["config"]["graph"] = graph is not None
+    fl = f1 - f0
+    if M <= 8:
+        bytes_cov = cov_algorithmic_bytes(T, fl, M, K)
+        out["roofline"] = {"bound": "hbm", "kernel": f"cov_dma_kernel<{M}, {min(K, 2)}> on rank 0's {fl} bins",
+                           "achieved": bytes_cov / (cov_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": bytes_cov / (cov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms, "per": "GPU"}
+    else:
+        issued = 6.0 * K * M * M * T * fl
+        out["roofline"] = {"bound": "fp32-mfma", "kernel": f"cov_mfma16_kernel on rank 0's {fl} bins",
+                           "achieved": issued / (cov_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": issued / (cov_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                           "avg_launch_ms": cov_ms, "per": "GPU"}
+    out["cpu_baseline"] = None      # reported at N = 1 only
     out["ranks"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "per_rank_stage_ms": gathered,
                     "message_bytes_per_rank": int(p_local.numel() * 4)}
     dist.destroy_process_group()
