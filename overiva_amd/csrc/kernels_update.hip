@@ -321,6 +321,24 @@ struct Sq {
     // value held by lane (i, c): same row, column c
     __device__ __forceinline__ R rowb(R v, int c) const { return __shfl(v, i * MP + c, G); }
     __device__ __forceinline__ Cx<R> rowb(Cx<R> v, int c) const { return {rowb(v.re, c), rowb(v.im, c)}; }
+    // the same with the column known at compile time: register-level (DPP) instead of the LDS crossbar -- a quad-permute
+    // broadcast inside every quad, and for 8 columns a half-row mirror that carries the right quad's value into the
+    // other one (written only to those banks).  2 VALU moves against a ds_bpermute round trip on a latency-bound chain.
+    template <int C>
+    __device__ __forceinline__ R rowb_c(R v) const {
+        if constexpr (MP == 8) {
+            const R t = dpp<(C & 3) * 0x55>(v);
+            return dpp_banks<kDppHalfMirror, (C < 4 ? 0xA : 0x5)>(t, t);
+        } else if constexpr (MP == 4) {
+            return dpp<(C & 3) * 0x55>(v);
+        } else if constexpr (MP == 2) {
+            return dpp<(C | (C << 2) | ((2 + C) << 4) | ((2 + C) << 6))>(v);     // rows are lane pairs of a quad
+        } else {
+            return v;
+        }
+    }
+    template <int C>
+    __device__ __forceinline__ Cx<R> rowb_c(Cx<R> v) const { return {rowb_c<C>(v.re), rowb_c<C>(v.im)}; }
     // value held by lane (r, j): same column, row r
     __device__ __forceinline__ R colb(R v, int r) const { return __shfl(v, r * MP + j, G); }
     __device__ __forceinline__ Cx<R> colb(Cx<R> v, int r) const { return {colb(v.re, r), colb(v.im, r)}; }
@@ -369,15 +387,32 @@ struct Sq {
     __device__ __forceinline__ Cx<R> at(Cx<R> v, int r, int c) const {
         return {__shfl(v.re, r * MP + c, G), __shfl(v.im, r * MP + c, G)};
     }
+    // the same for compile-time (r, c): with one bin per wavefront it is a v_readlane (scalar broadcast)
+    template <int RR, int CC>
+    __device__ __forceinline__ Cx<R> at_c(Cx<R> v) const {
+        if constexpr (G == 64) {
+            auto rl = [](R x) -> R {
+                if constexpr (sizeof(R) == 4) {
+                    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), RR * MP + CC));
+                } else {
+                    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), RR * MP + CC),
+                                            __builtin_amdgcn_readlane(__double2loint(x), RR * MP + CC));
+                }
+            };
+            return {rl(v.re), rl(v.im)};
+        } else {
+            return at(v, RR, CC);
+        }
+    }
     // inverse of a Hermitian positive definite matrix (identity outside M x M): in-place Gauss-Jordan, no pivot
     // search (every pivot of an HPD elimination is a positive Schur complement)
     __device__ __forceinline__ Cx<R> herm_inverse(Cx<R> A, int M) const {
-#pragma unroll
-        for (int k = 0; k < MP; ++k) {
+        static_for<MP>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
             if (k < M) {
                 const Cx<R> rk = colb(A, k);                 // A[k][j]
-                const Cx<R> ck = rowb(A, k);                 // A[i][k]
-                const Cx<R> d = cinv(rowb(rk, k));           // 1 / A[k][k]
+                const Cx<R> ck = rowb_c<k>(A);               // A[i][k]
+                const Cx<R> d = cinv(at_c<k, k>(A));         // 1 / A[k][k]
                 const Cx<R> rkd = cmul(rk, d);
                 if (i == k)
                     A = (j == k) ? d : rkd;
@@ -386,7 +421,7 @@ struct Sq {
                 else
                     cfms(A, ck, rkd);
             }
-        }
+        });
         return A;
     }
     // sum over all MP*MP lanes of the group
@@ -407,10 +442,10 @@ struct Sq {
     // inner index contribute
     __device__ __forceinline__ Cx<R> matmul(Cx<R> A, Cx<R> B, int M) const {
         Cx<R> acc = {R(0), R(0)};
-#pragma unroll
-        for (int m = 0; m < MP; ++m) {
-            if (m < M) cfma(acc, rowb(A, m), colb(B, m));
-        }
+        static_for<MP>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if (m < M) cfma(acc, rowb_c<m>(A), colb(B, m));
+        });
         return acc;
     }
     // Gauss-Jordan with partial pivoting over columns 0..npiv-1.  rhs is a per-row scalar replicated
@@ -418,11 +453,11 @@ struct Sq {
     // the lane's own row.
     __device__ __forceinline__ void gauss_jordan(Cx<R>& A, Cx<R>& rhs, int npiv, bool used, int (&perm)[MP],
                                                  Cx<R>& piv) const {
-#pragma unroll
-        for (int c = 0; c < MP; ++c) {
+        static_for<MP>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
             perm[c] = c;
             if (c < npiv) {
-                const Cx<R> aic = rowb(A, c);
+                const Cx<R> aic = rowb_c<c>(A);
                 // arg max over rows of |A[i][c]|^2, row index packed into the low mantissa bits
                 float mag = used ? 0.f : (float)(aic.re * aic.re + aic.im * aic.im);
                 unsigned key = (__float_as_uint(mag) & ~(unsigned)(MP - 1)) | (unsigned)(MP - 1 - i);
@@ -444,7 +479,7 @@ struct Sq {
                     if (j == c) A = {R(0), R(0)};
                 }
             }
-        }
+        });
     }
 };
 
@@ -635,16 +670,17 @@ __global__ __launch_bounds__(kBlock) void update_bg_kernel(UpdateArgs a) {
     for (int s = 0; s < K; ++s) {
         // Q = B_tt + B_tb B_bt on lanes i, j < K
         Cx<R> Q = B;
-#pragma unroll
-        for (int m = K; m < MP; ++m) {
-            if (m < M) cfma(Q, sq.rowb(B, m), sq.colb(B, m));
-        }
+        static_for<MP>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if (m >= K && m < M) cfma(Q, sq.template rowb_c<m>(B), sq.colb(B, m));
+        });
         // u_top = Q^-1 e_s
         Cx<R> u0, u1 = zero;
         if constexpr (K == 1) {
-            u0 = cinv(sq.at(Q, 0, 0));
+            u0 = cinv(sq.template at_c<0, 0>(Q));
         } else {
-            const Cx<R> q00 = sq.at(Q, 0, 0), q01 = sq.at(Q, 0, 1), q10 = sq.at(Q, 1, 0), q11 = sq.at(Q, 1, 1);
+            const Cx<R> q00 = sq.template at_c<0, 0>(Q), q01 = sq.template at_c<0, 1>(Q), q10 = sq.template at_c<1, 0>(Q),
+                        q11 = sq.template at_c<1, 1>(Q);
             Cx<R> det = cmul(q00, q11);
             cfms(det, q01, q10);
             const Cx<R> idet = cinv(det);
@@ -675,9 +711,10 @@ __global__ __launch_bounds__(kBlock) void update_bg_kernel(UpdateArgs a) {
         if (i == s) Tm = t;
         Cx<R> Jn;                          // lanes i < K, j >= K: J[i][j - K]
         if constexpr (K == 1) {
-            Jn = cmul(sq.colb(Tm, 0), cinv(sq.at(Tm, 0, 0)));
+            Jn = cmul(sq.colb(Tm, 0), cinv(sq.template at_c<0, 0>(Tm)));
         } else {
-            const Cx<R> t00 = sq.at(Tm, 0, 0), t01 = sq.at(Tm, 0, 1), t10 = sq.at(Tm, 1, 0), t11 = sq.at(Tm, 1, 1);
+            const Cx<R> t00 = sq.template at_c<0, 0>(Tm), t01 = sq.template at_c<0, 1>(Tm), t10 = sq.template at_c<1, 0>(Tm),
+                        t11 = sq.template at_c<1, 1>(Tm);
             const Cx<R> r0 = sq.colb(Tm, 0), r1 = sq.colb(Tm, 1);        // Tm[0][j], Tm[1][j]
             Cx<R> det = cmul(t00, t11);
             cfms(det, t01, t10);

@@ -2,6 +2,9 @@
 #pragma once
 #include "oiva_internal.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace oiva {
 
 constexpr float kEpsR = 1e-15f;  // reference overiva.py:170
@@ -99,6 +102,30 @@ __device__ __forceinline__ unsigned dpp(unsigned v) { return (unsigned)dpp32<CTR
 template <int CTRL>
 __device__ __forceinline__ double dpp(double v) {
     return __hiloint2double(dpp32<CTRL>(__double2hiint(v)), dpp32<CTRL>(__double2loint(v)));
+}
+// same, writing only the banks (groups of 4 lanes of a 16-lane row) selected by BANKS; the other lanes keep `old`
+template <int CTRL, int BANKS>
+__device__ __forceinline__ int dpp32_banks(int old, int x) {
+    return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xF, BANKS, false);
+}
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_banks(float old, float v) {
+    return __int_as_float(dpp32_banks<CTRL, BANKS>(__float_as_int(old), __float_as_int(v)));
+}
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double dpp_banks(double old, double v) {
+    return __hiloint2double(dpp32_banks<CTRL, BANKS>(__double2hiint(old), __double2hiint(v)),
+                            dpp32_banks<CTRL, BANKS>(__double2loint(old), __double2loint(v)));
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): loop indices that must be compile-time constants
+// (DPP controls, lane numbers of v_readlane)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 constexpr int kDppXor1 = 0xB1;   // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;   // quad_perm [2,3,0,1]
