@@ -83,6 +83,9 @@ int oiva_plan_destroy(oiva_plan *p);
  */
 int oiva_plan_set_x_host(oiva_plan *p, const void *X, long long row_pitch_bytes);
 int oiva_plan_set_x_dev(oiva_plan *p, const void *X_dev);
+/* _host_c128: as _host for a complex128 array (pitch in bytes of complex128 rows); the conversion to the device's
+ * complex64 runs on the GPU, so the host never touches the data (reference overiva.py:132 copies X once too). */
+int oiva_plan_set_x_host_c128(oiva_plan *p, const void *X, long long row_pitch_bytes);
 
 /*
  * Prologue, step 1: Cx[f] = (1/T) sum_t x x^H  (overiva.py:87).  Must follow set_x.
@@ -134,6 +137,9 @@ int oiva_plan_demix(oiva_plan *p, void *Y_host, long long row_pitch_bytes, int p
  * this plan or its destruction.  Hand it to oiva_plan_set_x_dev of another plan to chain two solves without a host
  * round trip (the PCA front-end of auxiva_pca.py:79-87).  Synchronous. */
 int oiva_plan_demix_dev(oiva_plan *p, int proj_back, void **Y_dev);
+/* As oiva_plan_demix, into a complex128 host array (the dtype overiva() returns for complex128 input); converted on
+ * the device. */
+int oiva_plan_demix_c128(oiva_plan *p, void *Y_host, long long row_pitch_bytes, int proj_back);
 
 /*
  * PCA front-end of auxiva_pca (auxiva_pca.py:71-81): W := the eigenvectors of the K largest eigenvalues of the input

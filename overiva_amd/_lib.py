@@ -40,6 +40,7 @@ SIGNATURES = {
     "oiva_plan_destroy": [_vp],
     "oiva_plan_set_x_host": [_vp, _vp, _ll],
     "oiva_plan_set_x_dev": [_vp, _vp],
+    "oiva_plan_set_x_host_c128": [_vp, _vp, _ll],
     "oiva_plan_covariance": [_vp],
     "oiva_plan_get_cx": [_vp, _vp, _i],
     "oiva_plan_set_w": [_vp, _vp, _i],
@@ -49,6 +50,7 @@ SIGNATURES = {
     "oiva_plan_update": [_vp, _vp, _i],
     "oiva_plan_demix": [_vp, _vp, _ll, _i],
     "oiva_plan_demix_dev": [_vp, _i, _vp],
+    "oiva_plan_demix_c128": [_vp, _vp, _ll, _i],
     "oiva_plan_set_w_pca": [_vp, _vp],
     "oiva_plan_get_w": [_vp, _vp, _i],
     "oiva_plan_sync": [_vp],

@@ -2,6 +2,8 @@
 // partial buffers, unpacking of packed Hermitian matrices.
 #include "oiva_device.h"
 
+#include <algorithm>
+
 namespace oiva {
 namespace {
 
@@ -97,7 +99,30 @@ __global__ __launch_bounds__(kBlock) void unpack_herm_kernel(const double* __res
     full[e] = v;
 }
 
+// complex128 <-> complex64 of a dense array (the device holds X and Y as complex64 whatever the caller's dtype)
+template <typename SRC, typename DST>
+__global__ __launch_bounds__(kBlock) void cast_complex_kernel(const SRC* __restrict__ in, DST* __restrict__ out, long long n) {
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < n; e += (long long)gridDim.x * kBlock) {
+        const SRC v = in[e];
+        DST o;
+        o.x = v.x;
+        o.y = v.y;
+        out[e] = o;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_cast_c128_to_c64(hipStream_t s, const double2* in, float2* out, long long n) {
+    const unsigned grid = (unsigned)std::min<long long>((n + kBlock - 1) / kBlock, 1 << 16);
+    hipLaunchKernelGGL((cast_complex_kernel<double2, float2>), dim3(grid), dim3(kBlock), 0, s, in, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_cast_c64_to_c128(hipStream_t s, const float2* in, double2* out, long long n) {
+    const unsigned grid = (unsigned)std::min<long long>((n + kBlock - 1) / kBlock, 1 << 16);
+    hipLaunchKernelGGL((cast_complex_kernel<float2, double2>), dim3(grid), dim3(kBlock), 0, s, in, out, n);
+    return hipGetLastError();
+}
 
 hipError_t launch_activation(hipStream_t s, const float* parts, int nparts, float* R, int T, int K, int model,
                              int F_total) {

@@ -197,6 +197,10 @@ hipError_t launch_ogive_step(hipStream_t s, const OgiveState& st, const void* Vp
 // ascending or nullptr
 hipError_t launch_pca_subspace(hipStream_t s, const double* Cx, float2* What, double2* What64, double* evals, int F, int M, int K);
 
+// dense complex128 <-> complex64 conversion on the device
+hipError_t launch_cast_c128_to_c64(hipStream_t s, const double2* in, float2* out, long long n);
+hipError_t launch_cast_c64_to_c128(hipStream_t s, const float2* in, double2* out, long long n);
+
 // unpack packed Hermitian float64 [nmat][M*M] -> full complex nmat x (M,M): complex64, or complex128 when out_f64
 hipError_t launch_unpack_herm(hipStream_t s, const double* packed, void* full, bool out_f64, long long nmat, int M);
 

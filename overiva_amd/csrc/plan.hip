@@ -457,6 +457,39 @@ int oiva_plan_set_x_host(oiva_plan* p, const void* X, long long row_pitch_bytes)
     return OIVA_OK;
 }
 
+int oiva_plan_set_x_host_c128(oiva_plan* p, const void* X, long long row_pitch_bytes) {
+    NEED(p && X, OIVA_ERR_ARG, "null argument");
+    DeviceGuard guard(p->device);
+    const size_t n_row = (size_t)p->F * p->M;
+    const size_t row = n_row * sizeof(double2);
+    const size_t pitch = row_pitch_bytes > 0 ? (size_t)row_pitch_bytes : row;
+    NEED(pitch >= row, OIVA_ERR_ARG, "row pitch smaller than one frame of this plan's bins");
+    if (!p->X_owned) HIP_TRY(hipMalloc(&p->X_owned, n_row * sizeof(float2) * p->T));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    // in slabs of frames through a staging buffer (<= 256 MB): the conversion of one slab overlaps nothing, but the
+    // footprint stays bounded and the host never touches the data (a NumPy astype of 1 GB costs 60 ms)
+    const int slab = (int)std::max<size_t>(1, std::min<size_t>((size_t)p->T, ((size_t)256 << 20) / row));
+    double2* stage = nullptr;
+    HIP_TRY(hipMalloc(&stage, row * slab));
+    hipError_t e = hipSuccess;
+    for (int t0 = 0; t0 < p->T && e == hipSuccess; t0 += slab) {
+        const int nt = std::min(slab, p->T - t0);
+        e = hipMemcpy2D(stage, row, static_cast<const char*>(X) + (size_t)t0 * pitch, pitch, row, nt, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_cast_c128_to_c64(p->stream, stage, p->X_owned + (size_t)t0 * n_row, (long long)nt * n_row);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    }
+    (void)hipFree(stage);
+    HIP_TRY(e);
+    if (p->X != p->X_owned) {             // switching from a borrowed array: captured graphs hold its pointer
+        int rc = drop_graph(p);
+        if (rc) return rc;
+    }
+    p->X = p->X_owned;
+    p->have_x = true;
+    p->have_cx = false;
+    return OIVA_OK;
+}
+
 int oiva_plan_set_x_dev(oiva_plan* p, const void* X_dev) {
     NEED(p && X_dev, OIVA_ERR_ARG, "null argument");
     NEED(((uintptr_t)X_dev & 15) == 0, OIVA_ERR_ARG, "device X must be 16-byte aligned");
@@ -637,6 +670,33 @@ int oiva_plan_demix(oiva_plan* p, void* Y_host, long long row_pitch_bytes, int p
     HIP_TRY(launch_demix_write(p->stream, p->X, p->What, sp, p->stg.nsplit, p->Y, p->T, p->F, p->M, p->K));
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemcpy2D(Y_host, pitch, p->Y, row, row, p->T, hipMemcpyDeviceToHost));
+    return OIVA_OK;
+}
+
+int oiva_plan_demix_c128(oiva_plan* p, void* Y_host, long long row_pitch_bytes, int proj_back) {
+    int rc = check_ready(p);
+    if (rc) return rc;
+    NEED(Y_host, OIVA_ERR_ARG, "null output");
+    DeviceGuard guard(p->device);
+    const size_t n_row = (size_t)p->F * p->K;
+    const size_t row = n_row * sizeof(double2);
+    const size_t pitch = row_pitch_bytes > 0 ? (size_t)row_pitch_bytes : row;
+    NEED(pitch >= row, OIVA_ERR_ARG, "row pitch smaller than one frame of this plan's bins");
+    void* ydev = nullptr;
+    if ((rc = oiva_plan_demix_dev(p, proj_back, &ydev))) return rc;
+    const int slab = (int)std::max<size_t>(1, std::min<size_t>((size_t)p->T, ((size_t)256 << 20) / row));
+    double2* stage = nullptr;
+    HIP_TRY(hipMalloc(&stage, row * slab));
+    hipError_t e = hipSuccess;
+    for (int t0 = 0; t0 < p->T && e == hipSuccess; t0 += slab) {
+        const int nt = std::min(slab, p->T - t0);
+        e = launch_cast_c64_to_c128(p->stream, static_cast<const float2*>(ydev) + (size_t)t0 * n_row, stage, (long long)nt * n_row);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+        if (e == hipSuccess)
+            e = hipMemcpy2D(static_cast<char*>(Y_host) + (size_t)t0 * pitch, pitch, stage, row, row, nt, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(stage);
+    HIP_TRY(e);
     return OIVA_OK;
 }
 

@@ -147,7 +147,7 @@ def overiva(
         epoch = 0
         while epoch < n_iter:
             if callback is not None and epoch % 10 == 0:  # overiva.py:142-148
-                callback(solver.demix(proj_back).astype(dtype, copy=False))
+                callback(solver.demix(proj_back, dtype))
             if callback is None:
                 step = n_iter - epoch
             else:
@@ -155,7 +155,7 @@ def overiva(
             solver.iterate(step)
             epoch += step
 
-        Y = solver.demix(proj_back).astype(dtype, copy=False)
+        Y = solver.demix(proj_back, dtype)
         if return_filters:
             return Y, solver.get_w().astype(dtype, copy=False)
         # surface a singular solve the way numpy.linalg.solve would (overiva.py:182)
@@ -195,8 +195,8 @@ class _SingleDevice:
     def iterate(self, n):
         self.plan.iterate(n)
 
-    def demix(self, proj_back):
-        return self.plan.demix(proj_back)
+    def demix(self, proj_back, dtype=np.complex64):
+        return self.plan.demix(proj_back, dtype=dtype)
 
     def get_w(self):
         return self.plan.get_w(self.wdtype)

@@ -78,6 +78,11 @@ class Plan:
         X = np.asarray(X)
         if X.ndim != 3 or X.shape[0] != self.T or X.shape[2] != self.M or X.shape[1] < f0 + self.F:
             raise ValueError(f"X has shape {X.shape}, plan expects ({self.T}, >={f0 + self.F}, {self.M})")
+        if X.dtype == np.complex128 and X.flags["C_CONTIGUOUS"]:      # converted on the device
+            pitch = X.shape[1] * self.M * 16
+            base = X.ctypes.data + f0 * self.M * 16
+            _lib.check(self.lib.oiva_plan_set_x_host_c128(self.h, C.c_void_p(base), pitch))
+            return
         if X.dtype != np.complex64 or not X.flags["C_CONTIGUOUS"]:
             X = np.ascontiguousarray(X[:, f0:f0 + self.F, :], dtype=np.complex64)
             f0 = 0
@@ -160,15 +165,18 @@ class Plan:
         return total.value, None
 
     # -- epilogue -----------------------------------------------------------------------------
-    def demix(self, proj_back=True, out=None, f0=0):
-        """Y (T, F, K) complex64; with ``out`` (T, F_any, K) writes bins [f0, f0+F) in place."""
+    def demix(self, proj_back=True, out=None, f0=0, dtype=np.complex64):
+        """Y (T, F, K) complex64 (or complex128: converted on the device); with ``out`` (T, F_any, K) writes bins
+        [f0, f0+F) in place, in the dtype of ``out``."""
         if out is None:
-            out = np.empty((self.T, self.F, self.K), np.complex64)
+            out = np.empty((self.T, self.F, self.K), dtype)
             f0 = 0
-        assert out.dtype == np.complex64 and out.flags["C_CONTIGUOUS"]
-        pitch = out.shape[1] * self.K * 8
-        base = out.ctypes.data + f0 * self.K * 8
-        _lib.check(self.lib.oiva_plan_demix(self.h, C.c_void_p(base), pitch, 1 if proj_back else 0))
+        assert out.dtype in (np.complex64, np.complex128) and out.flags["C_CONTIGUOUS"]
+        size = out.dtype.itemsize
+        pitch = out.shape[1] * self.K * size
+        base = out.ctypes.data + f0 * self.K * size
+        fn = self.lib.oiva_plan_demix if size == 8 else self.lib.oiva_plan_demix_c128
+        _lib.check(fn(self.h, C.c_void_p(base), pitch, 1 if proj_back else 0))
         return out
 
     def demix_device(self, proj_back=False):

@@ -178,8 +178,8 @@ class BinShardedSolver:
                 self.dist.all_gather_into_tensor(self.p_all, self.p_local, group=self.group)
                 self.engine.update(self.p_all)                     # rank-order sum, r, V, IP1, J
 
-    def demix(self, proj_back):
-        return self._gather_bins(self.engine.demix(proj_back), axis=1)
+    def demix(self, proj_back, dtype=np.complex64):
+        return self._gather_bins(self.engine.demix(proj_back), axis=1).astype(dtype, copy=False)
 
     def get_w(self):
         # gather first, judge afterwards: a singular bin on ONE rank must raise on EVERY rank, not leave the

@@ -422,6 +422,36 @@ def test_errors(oa):
         oa.overiva(Xz, n_src=2, n_iter=1, proj_back=False)
 
 
+def test_complex128_in_and_out_are_converted_on_the_device(oa):
+    """complex128 arrays cross the boundary as they are (the conversion to the device's complex64 and back runs on the
+    GPU): same bits as converting on the host, for X, for Y, for a bin shard of a larger array and for a callback"""
+    T, F, M, K = 130, 21, 4, 2
+    X128 = orc.synth_mixture(T, F, M, K, seed=4).astype(np.complex128) * (1 + 1e-9)      # not representable in complex64
+    X64 = X128.astype(np.complex64)
+    seen = []
+    Y128, W128 = oa.overiva(X128, n_src=K, n_iter=11, return_filters=True, callback=lambda Y: seen.append(Y.copy()))
+    Y64, W64 = oa.overiva(X64, n_src=K, n_iter=11, return_filters=True)
+    assert Y128.dtype == np.complex128 and W128.dtype == np.complex128 and Y64.dtype == np.complex64
+    assert np.array_equal(Y128, Y64.astype(np.complex128))
+    assert np.array_equal(W128.astype(np.complex64), W64)
+    assert len(seen) == 2 and all(y.dtype == np.complex128 and y.shape == (T, F, K) for y in seen)
+    with oa.Plan(T, 8, M, K, "laplace") as p:                  # bins 5..12 of the larger arrays
+        p.set_x(X128, f0=5)
+        p.covariance()
+        p.set_w(None)
+        p.iterate(2)
+        out = np.zeros((T, F, K), np.complex128)
+        p.demix(True, out=out, f0=5)
+        ref = p.demix(True)
+        assert np.array_equal(out[:, 5:13], ref.astype(np.complex128)) and not out[:, :5].any() and not out[:, 13:].any()
+    with oa.Plan(T, 8, M, K, "laplace") as q:
+        q.set_x(X64, f0=5)
+        q.covariance()
+        q.set_w(None)
+        q.iterate(2)
+        assert np.array_equal(q.demix(True), ref)
+
+
 def test_input_not_mutated_and_noncontiguous(oa):
     X = orc.synth_iid(64, 9, 4, seed=2)
     Xt = np.asfortranarray(X)            # non C-contiguous view of the same values
