@@ -88,6 +88,13 @@ class STFT:
         _lib.check(self.lib.oiva_stft_analysis(self.h, _lib.ptr(x), None, C.byref(dev)))
         return dev.value
 
+    def analysis_device(self, x):
+        """as ``analysis``, but X stays in device memory: a ``DeviceX`` that ``overiva()`` / ``auxiva_pca()`` /
+        ``Plan.set_x`` take in place of a host array (valid until the next call on this handle)"""
+        from .plan import DeviceX
+
+        return DeviceX(self.analysis(x, to_host=False), (self.n_frames, self.n_freq, self.n_chan), owner=self)
+
     def synthesis(self, Y):
         """Y (n_frames, n_freq, k) complex, k <= n_chan -> y (n_frames * hop, k) float32"""
         Y = np.ascontiguousarray(Y, dtype=np.complex64)

@@ -88,8 +88,10 @@ def test_audio_in_audio_out_separation():
             Y = p.demix(proj_back=True)
         y = s.synthesis(Y)
         X_host = s.analysis(x)
+        Y3 = oa.overiva(s.analysis_device(x), n_src=K, n_iter=30, proj_back=True)  # the drop-in call on a device tensor
     Y2 = oa.overiva(X_host, n_src=K, n_iter=30, proj_back=True)
     assert orc.rel_err(Y, Y2) < 1e-5                                               # device hand-over == host path
+    assert np.array_equal(Y3, Y2)
     assert y.shape == (T * hop, K)
 
     def sir(sig):                                                                  # best-permutation SIR via projections on the sources
