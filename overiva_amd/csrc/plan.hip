@@ -272,6 +272,9 @@ int build_graphs(oiva_plan* p) {
         e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         HIP_TRY(e);
+        // move the executable graph to the device now: otherwise its FIRST launch pays for that, inside whatever the
+        // caller is timing (a few percent of a 20-iteration run)
+        HIP_TRY(hipGraphUpload(*exec, p->stream));
         return OIVA_OK;
     };
     const bool pending = p->wscale_pending;
