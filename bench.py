@@ -270,9 +270,12 @@ def run_sharded(args):
         stream.synchronize()
         # per-rank stage breakdown (eager, events on the shared stream): power pass | all-gather | activation +
         # covariance + update
+        # roofline of the dominant kernel on this rank's shard: the covariance kernel alone, HIP events on the plan's
+        # stream (same definition as the single-GPU line, with this rank's number of bins).  Like the stage breakdown
+        # it runs before the wall-clock measurement, which then does not start on a cold GPU.
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         acc = [0.0, 0.0, 0.0]
-        nb = 5
+        nb = max(5, args.steps)
         for _ in range(nb):
             ev[0].record(stream)
             eng.power()
@@ -285,6 +288,8 @@ def run_sharded(args):
             for i in range(3):
                 acc[i] += ev[i].elapsed_time(ev[i + 1]) / nb
         breakdown = {"power_ms": acc[0], "all_gather_ms": acc[1], "activation_cov_update_ms": acc[2]}
+        cov_ms = eng.plan.t_time_stage("weighted_cov", 20)
+        stream.synchronize()
         graph = None
         spg = 8            # iterations per captured graph (kernels + the RCCL all-gather)
         # Capturing RCCL collectives in a graph was verified with one rank only (this pool has 1-GPU boxes), so
@@ -315,10 +320,6 @@ def run_sharded(args):
         stream.synchronize()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        # roofline of the dominant kernel on this rank's shard: the covariance kernel alone, HIP events on the plan's
-        # stream (same definition as the single-GPU line, with this rank's number of bins)
-        cov_ms = eng.plan.t_time_stage("weighted_cov", 20)
-        stream.synchronize()
     dist.barrier()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -393,7 +394,16 @@ def main():
     else:
         out = run_single(args)
     if out is not None:
-        print(json.dumps(out))
+        # the JSON line must be the LAST thing on stdout: RCCL writes its version banner to C stdio, which would
+        # otherwise be flushed at exit, i.e. after it
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
