@@ -241,11 +241,14 @@ def run_sharded(args):
     os.environ.setdefault("MASTER_PORT", "29533")
     rank = int(os.environ.setdefault("RANK", "0"))
     world = int(os.environ.setdefault("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", rank))
+    local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", device_id=dev)
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(args.backend)
     b = shard_bounds(F, world)
     f0, f1 = b[rank], b[rank + 1]
     X = synth_x_device(torch, dev, f0, f1)
@@ -387,6 +390,9 @@ def main():
     ap.add_argument("--no-other-mode", action="store_true", help="do not also time the other arithmetic mode")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (exercises RCCL + graph capture on 1 GPU)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the sharded path (nccl = RCCL; tests use gloo)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="tests on a 1-GPU box: every rank uses GPU 0 (needs --backend gloo: RCCL refuses two ranks on one device)")
     args = ap.parse_args()
     select_config(args.config)
     if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_sharded:

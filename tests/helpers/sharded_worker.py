@@ -1,0 +1,37 @@
+"""Worker of tests/test_sharded_2proc_gpu.py: one of N processes that share GPU 0 and shard the bins of one
+overiva() call between them -- the product's HipEngine and BinShardedSolver end to end, with the gloo backend
+carrying the collectives (RCCL refuses two ranks on one device).  Rank 0 writes the result."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def main():
+    out, T, F, M, K, model, precision, n_iter = sys.argv[1], *[int(a) for a in sys.argv[2:6]], sys.argv[6], sys.argv[7], int(sys.argv[8])
+    import torch
+    import torch.distributed as dist
+
+    import overiva_amd as oa
+    from oracle import overiva_oracle as orc          # test infrastructure: the input generator only
+
+    dist.init_process_group("gloo")
+    oa.set_device(0)                                   # every rank on the one GPU of the box
+    oa.set_precision(precision)
+    X = orc.synth_mixture(T, F, M, K, seed=11)
+    oa.enable_bin_sharding()
+    seen = []
+    Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, model=model, return_filters=True,
+                      callback=lambda y: seen.append(y.copy()))
+    oa.disable_bin_sharding()
+    if dist.get_rank() == 0:
+        np.savez(out, Y=Y, W=W, cb=np.stack(seen), world=dist.get_world_size())
+    dist.barrier()
+    dist.destroy_process_group()
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()
