@@ -263,10 +263,16 @@ def run_sharded(args):
         p_local = eng.exchange_buffer(ppr)
         p_all = eng.new_gather_buffer(world)
 
+        # transport of the per-iteration all-gather: RCCL through torch.distributed, or the library's push exchange
+        # (validated against the collective on every rank before it is used, else it falls back; exchange.py)
+        from overiva_amd.exchange import make_exchange
+
+        xchg = make_exchange(eng, dist, None, rank, world, p_local, p_all, prefer=args.exchange)
+        nparts = world * ppr
+
         def step():
             eng.power()
-            dist.all_gather_into_tensor(p_all, p_local)
-            eng.update(p_all)
+            eng.update_ptr(xchg.gather(), nparts)
 
         for _ in range(args.warmup):
             step()
@@ -283,9 +289,9 @@ def run_sharded(args):
             ev[0].record(stream)
             eng.power()
             ev[1].record(stream)
-            dist.all_gather_into_tensor(p_all, p_local)
+            gathered = xchg.gather()
             ev[2].record(stream)
-            eng.update(p_all)
+            eng.update_ptr(gathered, nparts)
             ev[3].record(stream)
             stream.synchronize()
             for i in range(3):
@@ -297,7 +303,7 @@ def run_sharded(args):
         spg = 8            # iterations per captured graph (kernels + the RCCL all-gather)
         # Capturing RCCL collectives in a graph was verified with one rank only (this pool has 1-GPU boxes), so
         # the multi-rank default is eager launches (host cost per step ~45 us < device time); --graph 2 opts in.
-        if args.graph >= 2 and args.steps >= spg:
+        if args.graph >= 2 and args.steps >= spg and xchg.name == "collective":
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=stream):
@@ -328,6 +334,8 @@ def run_sharded(args):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     W = eng.get_w()
     assert np.all(np.isfinite(W))
+    exchange_name = xchg.name
+    xchg.close()
     eng.close()
     gathered = [None] * world
     dist.all_gather_object(gathered, {"rank": rank, "bins": [f0, f1], **breakdown})
@@ -347,7 +355,8 @@ def run_sharded(args):
                            "frac": issued / (cov_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                            "avg_launch_ms": cov_ms, "per": "GPU"}
     out["cpu_baseline"] = None      # reported at N = 1 only
-    out["ranks"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "per_rank_stage_ms": gathered,
+    out["ranks"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "exchange": exchange_name,
+                    "per_rank_stage_ms": gathered,
                     "message_bytes_per_rank": int(p_local.numel() * 4)}
     dist.destroy_process_group()
     return out if rank == 0 else None
@@ -390,6 +399,9 @@ def main():
     ap.add_argument("--no-other-mode", action="store_true", help="do not also time the other arithmetic mode")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (exercises RCCL + graph capture on 1 GPU)")
+    ap.add_argument("--exchange", choices=["collective", "push"], default=os.environ.get("OIVA_EXCHANGE", "push"),
+                    help="all-gather of the partial powers when sharded: the library's push exchange (default; validated against "
+                         "the collective at start-up, falls back to it) or torch.distributed's collective (RCCL)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the sharded path (nccl = RCCL; tests use gloo)")
     ap.add_argument("--single-device", action="store_true",
                     help="tests on a 1-GPU box: every rank uses GPU 0 (needs --backend gloo: RCCL refuses two ranks on one device)")

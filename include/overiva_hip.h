@@ -142,6 +142,32 @@ int oiva_plan_demix_dev(oiva_plan *p, int proj_back, void **Y_dev);
 int oiva_plan_demix_c128(oiva_plan *p, void *Y_host, long long row_pitch_bytes, int proj_back);
 
 /*
+ * Push exchange of the per-rank partial powers between the GPUs of one node -- the all-gather in front of the activation
+ * (overiva.py:152-155) written for its 100 KB payload: every rank stores its part straight into every rank's gather
+ * buffer (fine-grained device memory shared through hipIpcMemHandle, peer stores over xGMI) and signals a counter; a
+ * rank's stream waits on its counter with a command-processor wait.  Same result layout as an all-gather (rank-major
+ * parts), so oiva_plan_update() takes the buffer as is.  Epochs count the exchanges, from 1, identically on every rank.
+ *   create   : allocate this rank's buffer for parts of part_bytes each
+ *   export   : OIVA_XCHG_HANDLE_BYTES bytes to hand to every other rank (any host-side transport)
+ *   connect  : map the other ranks' buffers; handles = world * OIVA_XCHG_HANDLE_BYTES bytes in rank order
+ *   push     : on `stream`, after whatever produced part_dev: store it into slot `rank` everywhere, then signal
+ *   wait     : `stream` waits until all `world` parts of this epoch are in this rank's buffer
+ *   gathered : the buffer to read after wait (world parts of the padded part size, rank order)
+ *   poll     : host-side check with a time-out (used to validate the transport before relying on it)
+ */
+#define OIVA_XCHG_MAX_RANKS 16
+#define OIVA_XCHG_HANDLE_BYTES 64
+typedef struct oiva_xchg oiva_xchg;
+int oiva_xchg_create(oiva_xchg **x, int device, int rank, int world, long long part_bytes);
+int oiva_xchg_export(oiva_xchg *x, void *handle);
+int oiva_xchg_connect(oiva_xchg *x, const void *handles);
+int oiva_xchg_push(oiva_xchg *x, void *stream, const void *part_dev, long long part_bytes, int epoch);
+int oiva_xchg_wait(oiva_xchg *x, void *stream, int epoch);
+int oiva_xchg_gathered(oiva_xchg *x, int epoch, void **gathered);
+int oiva_xchg_poll(oiva_xchg *x, int epoch, int timeout_ms, int *arrived);
+int oiva_xchg_destroy(oiva_xchg *x);
+
+/*
  * PCA front-end of auxiva_pca (auxiva_pca.py:71-81): W := the eigenvectors of the K largest eigenvalues of the input
  * covariance, in ascending order of the eigenvalue (numpy.linalg.eigh's w[:, :, -K:]), from a Jacobi eigensolver on
  * the device (float64, one wavefront per bin); the orthogonality constraint fills J as in oiva_plan_set_w.  A following

@@ -52,6 +52,14 @@ SIGNATURES = {
     "oiva_plan_demix_dev": [_vp, _i, _vp],
     "oiva_plan_demix_c128": [_vp, _vp, _ll, _i],
     "oiva_plan_set_w_pca": [_vp, _vp],
+    "oiva_xchg_create": [_vp, _i, _i, _i, _ll],
+    "oiva_xchg_export": [_vp, _vp],
+    "oiva_xchg_connect": [_vp, _vp],
+    "oiva_xchg_push": [_vp, _vp, _vp, _ll, _i],
+    "oiva_xchg_wait": [_vp, _vp, _i],
+    "oiva_xchg_gathered": [_vp, _i, _vp],
+    "oiva_xchg_poll": [_vp, _i, _i, _vp],
+    "oiva_xchg_destroy": [_vp],
     "oiva_plan_get_w": [_vp, _vp, _i],
     "oiva_plan_sync": [_vp],
     "oiva_plan_iterate_timed": [_vp, _i, _fp, _fp],

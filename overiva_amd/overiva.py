@@ -134,7 +134,8 @@ def overiva(
     if group is not None and isinstance(X, DeviceX):
         raise ValueError("a device-resident X cannot be sharded over ranks: pass the host array")
     if group is not None:
-        solver = sharded.BinShardedSolver(n_frames, n_freq, n_chan, n_src, model, group=group[0], precision=precision)
+        solver = sharded.BinShardedSolver(n_frames, n_freq, n_chan, n_src, model, group=group[0], precision=precision,
+                                          exchange=group[1] if len(group) > 1 else None)
     else:
         solver = _SingleDevice(n_frames, n_freq, n_chan, n_src, model, precision)
     try:

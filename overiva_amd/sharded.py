@@ -18,15 +18,17 @@ import numpy as np
 _active = None  # (group,) when overiva() should shard
 
 
-def enable_bin_sharding(group=None):
+def enable_bin_sharding(group=None, exchange=None):
     """Make ``overiva()`` shard bins over the ranks of ``group`` (default: the world group).
-    Every rank must then call ``overiva()`` with the same arguments; every rank gets the full result."""
+    Every rank must then call ``overiva()`` with the same arguments; every rank gets the full result.
+    ``exchange``: "collective" (torch.distributed all-gather, the default) or "push" (the library's own exchange,
+    validated against the collective before use; see exchange.py); None reads $OIVA_EXCHANGE."""
     import torch.distributed as dist
 
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
     global _active
-    _active = (group,)
+    _active = (group, exchange)
 
 
 def disable_bin_sharding():
@@ -113,6 +115,9 @@ class HipEngine:
     def update(self, parts):
         self.plan.update(parts.data_ptr(), parts.shape[0] // self.T)
 
+    def update_ptr(self, ptr, nparts):
+        self.plan.update(ptr, nparts)
+
     def demix(self, proj_back):
         return self.plan.demix(proj_back)
 
@@ -132,7 +137,7 @@ class HipEngine:
 class BinShardedSolver:
     """Same stage interface as the single-GPU solver in ``overiva.py``, over a process group."""
 
-    def __init__(self, T, F, M, K, model, group=None, engine_factory=None, device=None, precision="fast"):
+    def __init__(self, T, F, M, K, model, group=None, engine_factory=None, device=None, precision="fast", exchange=None):
         import torch.distributed as dist
 
         self.dist = dist
@@ -155,6 +160,15 @@ class BinShardedSolver:
         ppr = max(self.engine.power_parts(self.bounds[r + 1] - self.bounds[r]) for r in range(self.world))
         self.p_local = self.engine.exchange_buffer(ppr)
         self.p_all = self.engine.new_gather_buffer(self.world)
+        self.nparts = self.world * ppr
+        # transport of the per-iteration all-gather: torch.distributed's collective, or the library's push exchange
+        # when asked for and validated (exchange.py)
+        if hasattr(self.engine, "plan"):
+            from .exchange import make_exchange
+
+            self.xchg = make_exchange(self.engine, dist, group, self.rank, self.world, self.p_local, self.p_all, prefer=exchange)
+        else:
+            self.xchg = None
 
     # ---- stages ---------------------------------------------------------------------------------
     def set_x(self, X):
@@ -175,8 +189,11 @@ class BinShardedSolver:
         with self.engine.stream_ctx():
             for _ in range(n):
                 self.engine.power()                                # local sum_f |y|^2 -> p_local
-                self.dist.all_gather_into_tensor(self.p_all, self.p_local, group=self.group)
-                self.engine.update(self.p_all)                     # rank-order sum, r, V, IP1, J
+                if self.xchg is not None:
+                    self.engine.update_ptr(self.xchg.gather(), self.nparts)
+                else:
+                    self.dist.all_gather_into_tensor(self.p_all, self.p_local, group=self.group)
+                    self.engine.update(self.p_all)                 # rank-order sum, r, V, IP1, J
 
     def demix(self, proj_back, dtype=np.complex64):
         return self._gather_bins(self.engine.demix(proj_back), axis=1).astype(dtype, copy=False)
@@ -195,6 +212,9 @@ class BinShardedSolver:
         return W
 
     def close(self):
+        if getattr(self, "xchg", None) is not None:
+            self.engine.sync()
+            self.xchg.close()
         self.engine.close()
 
     # ---- helpers --------------------------------------------------------------------------------

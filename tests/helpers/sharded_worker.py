@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 
 def main():
     out, T, F, M, K, model, precision, n_iter = sys.argv[1], *[int(a) for a in sys.argv[2:6]], sys.argv[6], sys.argv[7], int(sys.argv[8])
+    exchange = sys.argv[9] if len(sys.argv) > 9 else "collective"
     import torch
     import torch.distributed as dist
 
@@ -21,7 +22,10 @@ def main():
     oa.set_device(0)                                   # every rank on the one GPU of the box
     oa.set_precision(precision)
     X = orc.synth_mixture(T, F, M, K, seed=11)
-    oa.enable_bin_sharding()
+    oa.enable_bin_sharding(exchange=exchange)
+    import warnings
+
+    warnings.simplefilter("error")                    # a fall-back to the collective must fail the test, not pass silently
     seen = []
     Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, model=model, return_filters=True,
                       callback=lambda y: seen.append(y.copy()))

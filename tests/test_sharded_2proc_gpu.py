@@ -15,25 +15,26 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, world, T, F, M, K, model, precision, n_iter, port):
+def _run(tmp_path, world, T, F, M, K, model, precision, n_iter, port, exchange="collective"):
     out = str(tmp_path / f"sharded_{world}.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "tests", "helpers", "sharded_worker.py"), out, str(T), str(F), str(M),
-           str(K), model, precision, str(n_iter)]
+           str(K), model, precision, str(n_iter), exchange]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return np.load(out)
 
 
+@pytest.mark.parametrize("exchange", ["collective", "push"])
 @pytest.mark.parametrize("world,F,model,precision", [(2, 128, "laplace", "precise"), (2, 128, "gauss", "fast"),
                                                      (3, 200, "laplace", "precise")])
-def test_processes_sharing_one_gpu(tmp_path, world, F, model, precision):
+def test_processes_sharing_one_gpu(tmp_path, world, F, model, precision, exchange):
     import overiva_amd as oa
     from oracle import overiva_oracle as orc
 
     T, M, K, n_iter = 300, 4, 2, 12
-    got = _run(tmp_path, world, T, F, M, K, model, precision, n_iter, 29600 + world)
+    got = _run(tmp_path, world, T, F, M, K, model, precision, n_iter, 29600 + world + (10 if exchange == "push" else 0), exchange)
     assert int(got["world"]) == world
     oa.set_precision(precision)
     try:
@@ -50,14 +51,15 @@ def test_processes_sharing_one_gpu(tmp_path, world, F, model, precision):
         assert orc.rel_err(got["W"], W) < 1e-5 and orc.rel_err(got["Y"], Y) < 1e-5
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("exchange", ["collective", "push"])
+def test_bench_two_ranks_on_one_gpu(exchange):
     """bench.py's N > 1 path with two real ranks (both on GPU 0, gloo transport): one JSON line from rank 0, as the last
     line of stdout, with the contract fields, a per-rank stage breakdown for both ranks and a finite value"""
     import json
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo",
-           "--single-device"]
+           "--master-port", "29611" if exchange == "collective" else "29612", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo",
+           "--single-device", "--exchange", exchange]
     r = subprocess.run(cmd, cwd=REPO, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -66,4 +68,5 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"] is None
     ranks = d["ranks"]["per_rank_stage_ms"]
+    assert d["ranks"]["exchange"] == exchange
     assert [x["rank"] for x in ranks] == [0, 1] and ranks[0]["bins"] == [0, 1024] and ranks[1]["bins"] == [1024, 2048]
