@@ -175,6 +175,9 @@ int oiva_xchg_destroy(oiva_xchg *x);
  * results after projection back do not depend on it.  evals_host: NULL or (F, M) float64, all eigenvalues ascending.
  */
 int oiva_plan_set_w_pca(oiva_plan *p, double *evals_host);
+/* init_eig of overiva.py:106-109: W := conj of the K principal eigenvectors of the input covariance, each with the
+ * phase numpy.linalg.eig (LAPACK zgeev) gives it -- largest component real and positive.  Same eigensolver. */
+int oiva_plan_set_w_eig(oiva_plan *p);
 /* W (F, M, K) complex64 (f64 = 0) or complex128 (f64 != 0) -- the view returned at overiva.py:201-202.
  * Synchronous.  Returns OIVA_ERR_NUMERIC if W holds a non-finite value (W is still copied out). */
 int oiva_plan_get_w(oiva_plan *p, void *W_host, int f64);

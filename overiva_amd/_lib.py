@@ -52,6 +52,7 @@ SIGNATURES = {
     "oiva_plan_demix_dev": [_vp, _i, _vp],
     "oiva_plan_demix_c128": [_vp, _vp, _ll, _i],
     "oiva_plan_set_w_pca": [_vp, _vp],
+    "oiva_plan_set_w_eig": [_vp],
     "oiva_xchg_create": [_vp, _i, _i, _i, _ll],
     "oiva_xchg_export": [_vp, _vp],
     "oiva_xchg_connect": [_vp, _vp],

@@ -37,9 +37,12 @@ __device__ __forceinline__ void pair_of(int n, int r, int k, int& p, int& q) {
     }
 }
 
+// lapack_phase: the convention of LAPACK's zgeev, which numpy.linalg.eig -- the call of the reference's init_eig,
+// overiva.py:106-109 -- inherits: every eigenvector is scaled by a phase that makes its largest component real (and
+// positive); W = conj(vecs) as the reference stores it.  Without it the vectors keep the Jacobi rotations' phases.
 __global__ __launch_bounds__(64) void pca_subspace_kernel(const double* __restrict__ Cx, float2* __restrict__ What,
                                                           double2* __restrict__ What64, double* __restrict__ evals, int F, int M,
-                                                          int K) {
+                                                          int K, int lapack_phase) {
     __shared__ Zd A[NMAX][NMAX + 1], V[NMAX][NMAX + 1], B[NMAX][NMAX + 1];
     __shared__ double rc[NMAX / 2];
     __shared__ Zd rs[NMAX / 2];
@@ -161,21 +164,40 @@ __global__ __launch_bounds__(64) void pca_subspace_kernel(const double* __restri
         What[o] = make_float2((float)v.re, (float)v.im);
     }
     __syncthreads();
+    if (lapack_phase) {
+        if (tid < M) {                                   // column tid: phase of its largest component (first on ties)
+            int kmax = 0;
+            double best = -1.;
+            for (int r = 0; r < M; ++r) {
+                const double m = V[r][tid].re * V[r][tid].re + V[r][tid].im * V[r][tid].im;
+                if (m > best) {
+                    best = m;
+                    kmax = r;
+                }
+            }
+            const double a = sqrt(best);
+            B[0][tid] = a > 0. ? Zd{V[kmax][tid].re / a, -V[kmax][tid].im / a} : Zd{1., 0.};   // conj(v_k) / |v_k|
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < M * M; e += 64) {
         const int r = e / M, j = e % M;
         const int col = rank[j] - (M - K);
         if (col >= 0) {
+            Zd v = V[r][j];
+            if (lapack_phase) v = zconj(zmul(v, B[0][j]));   // largest component real, then W = conj(vecs)
             const size_t o = ((size_t)f * M + r) * M + col;
-            What64[o] = make_double2(V[r][j].re, V[r][j].im);
-            What[o] = make_float2((float)V[r][j].re, (float)V[r][j].im);
+            What64[o] = make_double2(v.re, v.im);
+            What[o] = make_float2((float)v.re, (float)v.im);
         }
     }
 }
 
 }  // namespace
 
-hipError_t launch_pca_subspace(hipStream_t s, const double* Cx, float2* What, double2* What64, double* evals, int F, int M, int K) {
-    hipLaunchKernelGGL(pca_subspace_kernel, dim3(F), dim3(64), 0, s, Cx, What, What64, evals, F, M, K);
+hipError_t launch_pca_subspace(hipStream_t s, const double* Cx, float2* What, double2* What64, double* evals, int F, int M, int K,
+                               bool lapack_phase) {
+    hipLaunchKernelGGL(pca_subspace_kernel, dim3(F), dim3(64), 0, s, Cx, What, What64, evals, F, M, K, lapack_phase ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -194,8 +194,9 @@ hipError_t launch_ogive_step(hipStream_t s, const OgiveState& st, const void* Vp
                              int M, double mu, double tol);
 
 // W_hat = [eigenvectors of the K largest eigenvalues of Cx, ascending | [0; -I]]   (auxiva_pca.py:75-81); evals (F, M)
-// ascending or nullptr
-hipError_t launch_pca_subspace(hipStream_t s, const double* Cx, float2* What, double2* What64, double* evals, int F, int M, int K);
+// ascending or nullptr; lapack_phase: W = conj(vecs) with every vector's largest component real (overiva.py:106-109)
+hipError_t launch_pca_subspace(hipStream_t s, const double* Cx, float2* What, double2* What64, double* evals, int F, int M, int K,
+                               bool lapack_phase);
 
 // dense complex128 <-> complex64 conversion on the device
 hipError_t launch_cast_c128_to_c64(hipStream_t s, const double2* in, float2* out, long long n);

@@ -562,12 +562,17 @@ int oiva_plan_set_w(oiva_plan* p, const void* W0_host, int f64) {
     return OIVA_OK;
 }
 
-int oiva_plan_set_w_pca(oiva_plan* p, double* evals_host) {
+static int set_w_from_eigenvectors(oiva_plan* p, double* evals_host, bool lapack_phase);
+
+int oiva_plan_set_w_pca(oiva_plan* p, double* evals_host) { return set_w_from_eigenvectors(p, evals_host, false); }
+int oiva_plan_set_w_eig(oiva_plan* p) { return set_w_from_eigenvectors(p, nullptr, true); }
+
+static int set_w_from_eigenvectors(oiva_plan* p, double* evals_host, bool lapack_phase) {
     NEED(p, OIVA_ERR_ARG, "null plan");
     NEED(p->have_cx, OIVA_ERR_STATE, "input covariance not computed (oiva_plan_covariance)");
     DeviceGuard guard(p->device);
     double* evals = evals_host ? p->scratch_p : nullptr;       // scratch_p holds at least K * F * M * M doubles
-    HIP_TRY(launch_pca_subspace(p->stream, p->Cx, p->What, p->What64, evals, p->F, p->M, p->K));
+    HIP_TRY(launch_pca_subspace(p->stream, p->Cx, p->What, p->What64, evals, p->F, p->M, p->K, lapack_phase));
     p->what64_valid = true;
     p->wscale_pending = false;
     p->have_w = true;

@@ -62,10 +62,9 @@ def _complex_dtype(X):
 
 
 def eig_init(Cx, n_src):
-    """W0 from the principal eigenvectors of the input covariance (reference overiva.py:106-109).
-
-    Stays on the host: eigenvector phases are LAPACK's choice and the reference keeps them.
-    """
+    """W0 from the principal eigenvectors of the input covariance (reference overiva.py:106-109), with host LAPACK as
+    in the reference.  The single-GPU path uses the device eigensolver instead (``Plan.set_w_eig``: same vectors, same
+    phase convention -- largest component real); this host form serves the bin-sharded solver."""
     vals, vecs = np.linalg.eig(np.asarray(Cx, dtype=np.complex128))
     F, M, _ = Cx.shape
     W0 = np.empty((F, M, n_src), dtype=np.complex128)
@@ -141,9 +140,12 @@ def overiva(
     try:
         solver.set_x(X)
         solver.covariance()
-        if W0 is None and init_eig:
-            W0 = eig_init(solver.get_cx(), n_src)
-        solver.set_w(W0)
+        if W0 is None and init_eig and hasattr(solver, "set_w_eig"):
+            solver.set_w_eig()                      # overiva.py:106-109 on the device
+        else:
+            if W0 is None and init_eig:
+                W0 = eig_init(solver.get_cx(), n_src)
+            solver.set_w(W0)
 
         epoch = 0
         while epoch < n_iter:
@@ -192,6 +194,9 @@ class _SingleDevice:
 
     def set_w(self, W0):
         self.plan.set_w(W0)
+
+    def set_w_eig(self):
+        self.plan.set_w_eig()
 
     def iterate(self, n):
         self.plan.iterate(n)

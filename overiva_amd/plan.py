@@ -122,6 +122,11 @@ class Plan:
         _lib.check(self.lib.oiva_plan_set_w_pca(self.h, _lib.ptr(ev) if ev is not None else None))
         return ev
 
+    def set_w_eig(self):
+        """``init_eig`` of overiva.py:106-109 on the device: W := conj of the K principal eigenvectors of the input
+        covariance with LAPACK's phase convention (largest component real)"""
+        _lib.check(self.lib.oiva_plan_set_w_eig(self.h))
+
     # -- iteration ----------------------------------------------------------------------------
     def iterate(self, n=1):
         _lib.check(self.lib.oiva_plan_iterate(self.h, int(n)))
