@@ -86,6 +86,12 @@ BIG_CASES = [
     ("h", 200, 64, 4, 2),
     ("i", 200, 64, 8, 2),
     ("j", 208, 64, 6, 3),
+    # channel counts without a small fixture: odd counts (generic covariance kernel), determined 8 x 8, and the padded
+    # 9..16-channel path with background channels
+    ("k", 160, 24, 7, 2),
+    ("l", 160, 16, 12, 3),
+    ("m", 144, 24, 8, 8),
+    ("n", 128, 20, 5, 5),
 ]
 BIG_ITERS = (1, 5, 20)
 
