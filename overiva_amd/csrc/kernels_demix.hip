@@ -58,7 +58,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // ---------------------------------------------------------------------------------------------
 // power: block = 4 waves x 16 bins = 64 bins, 4 frame phases per wave, frames [t_begin, t_begin+tcp)
 // ---------------------------------------------------------------------------------------------
-constexpr int kPowUnroll = 4;
+constexpr int kPowUnroll = 2;
 
 template <int M, int KP>
 __global__ __launch_bounds__(kBlock) void power_kernel(const float2* __restrict__ X, const float2* __restrict__ What,

@@ -166,11 +166,16 @@ void choose_pow_geom(oiva_plan* p, int nsplit_req) {
     const int nz = ceil_div(p->K, g.kp);
     int nsplit = nsplit_req;
     if (nsplit <= 0) {
-        // 3 workgroups (12 waves) per CU: more resident waves thrash the 32 KB L1 (measured: 2048
-        // workgroups run 3x slower than 768 on the headline shape), fewer expose HBM latency
-        // and at least 64 frames (16 steps per wave) per workgroup: each one loads its W first (measured on a
-        // 256-bin shard: 62 splits 13.5 us, 167 splits 15.9 us)
-        nsplit = pick_splits(p->n_cu * 3, g.nb * nz, p->T, 64);
+        // Workgroups so that about 48 KB of X are in flight per CU: a wave keeps two steps (2 x 4 frames x 16 bins x 8M
+        // bytes) in flight, i.e. 12 / M workgroups per CU -- 1.5 at 8 channels, 3 at 4, 0.75 at 16.  Measured at 2048 bins
+        // x 4000 frames on the kernel itself and on the pure-read form of its geometry (tools/membench.hip, pattern P):
+        // 8 channels 12 splits (384 workgroups) 88-90 us, 16: 91, 24: 92, 8: 106 (four steps in flight and 24 splits, as in
+        // round 1: 94-96 us); 4 channels 24 splits 40.7 us, 12: 46; 2 channels 24 splits 21.8, 12: 35; 16 channels / 2
+        // sources 6 splits 172 us, 12: 234.  More resident waves thrash the 32 KB L1, fewer expose HBM latency.  At
+        // least 64 frames (16 steps per wave) per workgroup: each one loads its W first (256-bin shard: 62 splits
+        // 13.5 us, 167 splits 15.9 us).
+        // (counted per source pass: with 8 sources in two passes, 12 splits 112 us, 6 splits 127-137 us)
+        nsplit = pick_splits(std::max(p->n_cu / 2, p->n_cu * 12 / std::max(p->M, 1)), g.nb, p->T, 64);
     }
     int tcp = round_up(ceil_div(p->T, nsplit), 4);
     tcp = std::min(std::max(tcp, 4), kPowMaxFrames);
