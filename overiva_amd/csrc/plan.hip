@@ -163,7 +163,6 @@ void choose_pow_geom(oiva_plan* p, int nsplit_req) {
     PowGeom g;
     g.nb = ceil_div(p->F, kBinsPerWave * kWaves);
     g.kp = pow_sources_per_pass(p->M, p->K);
-    const int nz = ceil_div(p->K, g.kp);
     int nsplit = nsplit_req;
     if (nsplit <= 0) {
         // Workgroups so that about 48 KB of X are in flight per CU: a wave keeps two steps (2 x 4 frames x 16 bins x 8M
