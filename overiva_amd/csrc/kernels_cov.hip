@@ -529,9 +529,8 @@ hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt,
             return hipGetLastError();
         });
     return dispatch_cov<float>(M, kc, R == nullptr, [&](CovKernel<float> kern, int KC) {
-        kern<<<dim3(g.nbg, g.nsplit, (K + KC - 1) / KC), dim3(kBlock), 0, s>>>(X, R, wscale, model, raw,
-                                                                             static_cast<float*>(Vpart), T, F, K, g.tc);
-        return hipGetLastError();
+        return launch_dominant(kern, dim3(g.nbg, g.nsplit, (K + KC - 1) / KC), dim3(kBlock), 0, s, X, R, wscale, model, raw,
+                               static_cast<float*>(Vpart), T, F, K, g.tc);
     });
 }
 

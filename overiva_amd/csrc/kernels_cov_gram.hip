@@ -251,9 +251,8 @@ hipError_t launch_one(hipStream_t s, const float2* X, const float* R, float* wsc
                       int T, int F, int M, int K, const CovGeom& g) {
     const long long tiles = ((long long)F * M * 2 + 15) / 16;
     dim3 grid((unsigned)((tiles + kTilesPerBlock - 1) / kTilesPerBlock), g.nsplit, (K + KC - 1) / KC);
-    hipLaunchKernelGGL((cov_gram_kernel<KC>), grid, dim3(kBlock), 0, s, reinterpret_cast<const float*>(X), R, wscale, model,
-                       raw, static_cast<double*>(Vpart), T, F, M, K, g.tc);
-    return hipGetLastError();
+    return launch_dominant(cov_gram_kernel<KC>, grid, dim3(kBlock), 0, s, reinterpret_cast<const float*>(X), R, wscale, model,
+                           raw, static_cast<double*>(Vpart), T, F, M, K, g.tc);
 }
 
 }  // namespace

@@ -172,15 +172,15 @@ hipError_t launch_planar(hipStream_t s, const float2* X, const float* Wt, void* 
     dim3 grid(F, nsplit, unit ? 1 : (K + kw - 1) / kw);
     REAL* V = static_cast<REAL*>(Vpart);
     if (unit)
-        cov_mfma16_kernel<REAL, 1, true><<<grid, dim3(64), 0, s>>>(X, Wt, V, T, F, M, K, Kp, tc);
+        return launch_dominant(cov_mfma16_kernel<REAL, 1, true>, grid, dim3(64), 0, s, X, Wt, V, T, F, M, K, Kp, tc);
     else if (kw == 2)
-        cov_mfma16_kernel<REAL, 2, false><<<grid, dim3(64), 0, s>>>(X, Wt, V, T, F, M, K, Kp, tc);
+        return launch_dominant(cov_mfma16_kernel<REAL, 2, false>, grid, dim3(64), 0, s, X, Wt, V, T, F, M, K, Kp, tc);
     else if (kw == 4)
-        cov_mfma16_kernel<REAL, 4, false><<<grid, dim3(64), 0, s>>>(X, Wt, V, T, F, M, K, Kp, tc);
+        return launch_dominant(cov_mfma16_kernel<REAL, 4, false>, grid, dim3(64), 0, s, X, Wt, V, T, F, M, K, Kp, tc);
     else if (kw == 8)
-        cov_mfma16_kernel<REAL, 8, false><<<grid, dim3(64), 0, s>>>(X, Wt, V, T, F, M, K, Kp, tc);
+        return launch_dominant(cov_mfma16_kernel<REAL, 8, false>, grid, dim3(64), 0, s, X, Wt, V, T, F, M, K, Kp, tc);
     else if constexpr (kMaxKw >= 16)
-        cov_mfma16_kernel<REAL, 16, false><<<grid, dim3(64), 0, s>>>(X, Wt, V, T, F, M, K, Kp, tc);
+        return launch_dominant(cov_mfma16_kernel<REAL, 16, false>, grid, dim3(64), 0, s, X, Wt, V, T, F, M, K, Kp, tc);
     return hipGetLastError();
 }
 
