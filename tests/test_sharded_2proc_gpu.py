@@ -21,7 +21,7 @@ def _run(tmp_path, world, T, F, M, K, model, precision, n_iter, port, exchange="
            "--master-port", str(port), os.path.join(REPO, "tests", "helpers", "sharded_worker.py"), out, str(T), str(F), str(M),
            str(K), model, precision, str(n_iter), exchange]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return np.load(out)
 
@@ -60,7 +60,7 @@ def test_bench_two_ranks_on_one_gpu(exchange):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29611" if exchange == "collective" else "29612", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--backend", "gloo",
            "--single-device", "--exchange", exchange]
-    r = subprocess.run(cmd, cwd=REPO, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=REPO, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     d = json.loads(lines[-1])
