@@ -207,6 +207,37 @@ int oiva_plan_use_graph(oiva_plan *p, int enable);
 int oiva_plan_set_precision(oiva_plan *p, int flags);
 
 /*
+ * X-resident iteration: the loop body of overiva.py:138-190 (demix + power, activation, weighted covariance, IP1
+ * solve + normalisation, orthogonal-constraint update of J) fused into ONE persistent launch per oiva_plan_iterate
+ * call, with the plan's slice of X held in the chip's registers + LDS for all n iterations (X leaves HBM once per
+ * call instead of twice per iteration).  Applies when the slice fits on chip -- 16 bins x <= 256 frames per compute
+ * unit: BASELINE configs[1], one rank's 256-bin shard of the headline shape -- with 4 or 8 channels, 1 or 2 sources
+ * (K < M) and a float32 covariance pass; see csrc/resident_kernel.inc.
+ *   oiva_plan_set_resident   : enable = 1 turns it on (OIVA_ERR_ARG when the shape does not qualify), 0 off.
+ *                              With it on, oiva_plan_iterate is synchronous; a launch whose workgroups could not all
+ *                              become resident gives up after the time-out WITHOUT having changed W, the plan falls
+ *                              back to the four-launch path for that call and all later ones, and the reason is kept
+ *                              (info[8]).
+ *   oiva_plan_resident_info  : info[0] shape qualifies, [1] enabled, [2] bin groups, [3] frame splits, [4] frames per
+ *                              split, [5] frames per lane, [6] of them in registers, [7] LDS bytes per workgroup,
+ *                              [8] give-up code of the last failed launch (0: none), [9] resident launches so far,
+ *                              [10] fall-backs so far, [11] the frames of X each compute unit holds, in bytes
+ *   oiva_plan_resident_phases: average duration in microseconds, over the iterations of the last resident launch
+ *                              (at most 256), of the phases of workgroup 0, from the 100 MHz clock read inside the
+ *                              kernel: [0] demix + power, [1] wait for the column's parts, [2] activation,
+ *                              [3] covariance, [4] wait for the row's partials, [5] per-bin update, [6] wait for the
+ *                              row's demixing vectors; *n_iter = iterations covered (0: nothing recorded)
+ *   oiva_plan_resident_debug : test hooks -- time-out of a wait in milliseconds (0: default 2000), and the index of a
+ *                              workgroup that never publishes (-1: none), which makes the launch give up
+ */
+#define OIVA_RESIDENT_INFO 12
+#define OIVA_RESIDENT_PHASES 7
+int oiva_plan_set_resident(oiva_plan *p, int enable);
+int oiva_plan_resident_info(oiva_plan *p, int *info /* OIVA_RESIDENT_INFO ints */);
+int oiva_plan_resident_phases(oiva_plan *p, double *phase_us /* OIVA_RESIDENT_PHASES */, int *n_iter);
+int oiva_plan_resident_debug(oiva_plan *p, int timeout_ms, int stall_block);
+
+/*
  * Test-only stage access (per-kernel parity tests call these through the same ABI).
  * Stages run on the plan's current state; getters synchronise.
  */

@@ -18,6 +18,8 @@ N_STAGES = 4
 # oiva_plan_set_precision flags (include/overiva_hip.h)
 PREC_FAST, PREC_UPDATE_F64, PREC_UPDATE_ROWS, PREC_COV_F64 = 0, 1, 2, 4
 PREC_PRECISE = PREC_UPDATE_F64 | PREC_COV_F64
+PREC_MIXED = PREC_UPDATE_F64
+PREC_BY_NAME = {"fast": PREC_FAST, "mixed": PREC_MIXED, "precise": PREC_PRECISE}
 STAGE_NAMES = ("demix_power", "activation", "weighted_cov", "ip_update")
 
 
@@ -69,6 +71,10 @@ SIGNATURES = {
     "oiva_plan_set_pow_splits": [_vp, _i],
     "oiva_plan_use_graph": [_vp, _i],
     "oiva_plan_set_precision": [_vp, _i],
+    "oiva_plan_set_resident": [_vp, _i],
+    "oiva_plan_resident_info": [_vp, C.POINTER(_i)],
+    "oiva_plan_resident_phases": [_vp, C.POINTER(C.c_double), C.POINTER(_i)],
+    "oiva_plan_resident_debug": [_vp, _i, _i],
     "oiva_test_set_rinv": [_vp, _vp],
     "oiva_test_get_rinv": [_vp, _vp, _vp],
     "oiva_test_run_weighted_cov": [_vp],

@@ -10,6 +10,7 @@ depend on them (a phase of a principal component becomes a phase of a demixed so
 import numpy as np
 
 from . import overiva as _ov
+from . import sharded
 from .plan import Plan
 
 
@@ -30,7 +31,7 @@ def auxiva_pca(X, n_src=None, **kwargs):
     kwargs.pop("proj_back")                                                   # auxiva_pca.py:86
     kwargs.pop("return_filters", None)   # the reference would hand a tuple to projection_back and fail
 
-    precision = _ov.get_precision()
+    precision = _ov.resolve_precision(dtype, n_chan)
     with Plan(n_frames, n_freq, n_chan, n_src, "laplace", device=_ov.get_device()) as full:
         full.set_precision(precision)
         full.set_x(X)
@@ -38,8 +39,11 @@ def auxiva_pca(X, n_src=None, **kwargs):
         if n_src < n_chan:
             full.set_w_pca()                                                  # auxiva_pca.py:75: eigh, w[:, :, -n_src:]
             P = full.get_w(np.complex128)                                     # (F, M, K) principal subspace
-            new_X = full.demix_device(proj_back=False)                        # x -> P^H x, auxiva_pca.py:79-81
-            new_X.dtype = np.dtype(dtype)
+            if sharded.active_group() is not None:                            # a device-resident tensor cannot be sharded over ranks
+                new_X = full.demix(proj_back=False, dtype=dtype)
+            else:
+                new_X = full.demix_device(proj_back=False)                    # x -> P^H x, auxiva_pca.py:79-81
+                new_X.dtype = np.dtype(dtype)
         else:
             P = None
             new_X = X

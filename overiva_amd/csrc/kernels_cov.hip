@@ -15,60 +15,10 @@
 #include <cstdint>
 
 #include "oiva_device.h"
+#include "cov_arith.h"
 
 namespace oiva {
 namespace {
-
-// acc[kk][*] += w[kk] * pack(x x^H); ACC = float, or double for the float64 accumulation mode (products of
-// float32 data are then exact, as in the reference's complex128 product at overiva.py:179)
-template <int M, int KC, bool UNIT, typename ACC>
-__device__ __forceinline__ void accumulate(ACC (&acc)[KC][M * M], const ACC (&xr)[M], const ACC (&xi)[M],
-                                           const ACC (&w)[KC]) {
-    if constexpr (KC == 1) {
-        // one source: scale x once, then 4 FMAs per complex pair
-        ACC sr[M], si[M];
-#pragma unroll
-        for (int c = 0; c < M; ++c) {
-            sr[c] = xr[c] * w[0];   // UNIT: w is 1 (live frame) or 0 (clamped tail frame)
-            si[c] = xi[c] * w[0];
-        }
-#pragma unroll
-        for (int c = 0; c < M; ++c) acc[0][c] = fma(sr[c], xr[c], fma(si[c], xi[c], acc[0][c]));
-        int a = M;
-#pragma unroll
-        for (int c = 0; c < M; ++c) {
-#pragma unroll
-            for (int d = c + 1; d < M; ++d) {
-                acc[0][a] = fma(sr[c], xr[d], fma(si[c], xi[d], acc[0][a]));           // Re x_c conj(x_d)
-                acc[0][a + 1] = fma(si[c], xr[d], fma(-sr[c], xi[d], acc[0][a + 1]));  // Im x_c conj(x_d)
-                a += 2;
-            }
-        }
-    } else {
-        // several sources: form each product once, one FMA per source
-#pragma unroll
-        for (int c = 0; c < M; ++c) {
-            const ACC p = fma(xr[c], xr[c], xi[c] * xi[c]);
-#pragma unroll
-            for (int kk = 0; kk < KC; ++kk) acc[kk][c] = fma(w[kk], p, acc[kk][c]);
-        }
-        int a = M;
-#pragma unroll
-        for (int c = 0; c < M; ++c) {
-#pragma unroll
-            for (int d = c + 1; d < M; ++d) {
-                const ACC pre = fma(xr[c], xr[d], xi[c] * xi[d]);
-                const ACC pim = fma(xi[c], xr[d], -(xr[c] * xi[d]));
-#pragma unroll
-                for (int kk = 0; kk < KC; ++kk) {
-                    acc[kk][a] = fma(w[kk], pre, acc[kk][a]);
-                    acc[kk][a + 1] = fma(w[kk], pim, acc[kk][a + 1]);
-                }
-                a += 2;
-            }
-        }
-    }
-}
 
 constexpr int kCovUnroll = 2;            // frame steps in flight per wave
 constexpr int kChunk = 16;               // accumulators combined per LDS round
@@ -77,14 +27,17 @@ constexpr int kLdsStride = kBlock + 1;   // +1: conflict-free transposed read
 // Combine the 16 frame phases of a workgroup (tid = q*16 + b) in rounds of kChunk accumulators through
 // LDS and store one packed partial per (frame split, bin, source):
 //   write lds[a][tid]; thread (bb = tid/16, aa = tid%16) sums lds[aa][qq*16 + bb] over qq (fixed order).
+// The sum over the phases and the stored partial are float64 whatever the accumulator type: a float32 lane chain
+// covers T / (16 nsplit) frames, and adding 16 (then nsplit) of them in float32 would cost as much accuracy again as
+// the chains themselves (measured on the reference's fixtures: 1.5-4 of its complex64 floors -> below one).
 template <int M, int KC, typename ACC, typename At>
-__device__ __forceinline__ void reduce_and_store_at(At&& at, ACC* lds, ACC* __restrict__ Vpart, int F, int K, int k0) {
+__device__ __forceinline__ void reduce_and_store_at(At&& at, ACC* lds, double* __restrict__ Vpart, int F, int K, int k0) {
     constexpr int NA = M * M;
     constexpr int NACC = NA * KC;
     const int tid = threadIdx.x;
     const int bb = tid >> 4, aa = tid & 15;
     const int fo = blockIdx.x * kBinsPerWave + bb;
-    ACC* out = Vpart + (((size_t)blockIdx.y * F + fo) * K + k0) * NA;
+    double* out = Vpart + (((size_t)blockIdx.y * F + fo) * K + k0) * NA;
 #pragma unroll
     for (int r0 = 0; r0 < NACC; r0 += kChunk) {
         __syncthreads();
@@ -93,9 +46,9 @@ __device__ __forceinline__ void reduce_and_store_at(At&& at, ACC* lds, ACC* __re
             if (r0 + a < NACC) lds[a * kLdsStride + tid] = at(r0 + a);      // accumulator kk * NA + a, compile-time index
         }
         __syncthreads();
-        ACC s = 0;
+        double s = 0.;
 #pragma unroll
-        for (int qq = 0; qq < 16; ++qq) s += lds[aa * kLdsStride + qq * 16 + bb];
+        for (int qq = 0; qq < 16; ++qq) s += (double)lds[aa * kLdsStride + qq * 16 + bb];
         const int e = r0 + aa;          // accumulator index = kk*NA + a
         const int kk = e / NA;          // constant-folded per round when NA % 16 == 0
         if (e < NACC && fo < F && k0 + kk < K) out[e] = s;
@@ -103,7 +56,7 @@ __device__ __forceinline__ void reduce_and_store_at(At&& at, ACC* lds, ACC* __re
 }
 
 template <int M, int KC, typename ACC>
-__device__ __forceinline__ void reduce_and_store(const ACC (&acc)[KC][M * M], ACC* lds, ACC* __restrict__ Vpart,
+__device__ __forceinline__ void reduce_and_store(const ACC (&acc)[KC][M * M], ACC* lds, double* __restrict__ Vpart,
                                                  int F, int K, int k0) {
     reduce_and_store_at<M, KC, ACC>([&](int e) { return acc[e / (M * M)][e % (M * M)]; }, lds, Vpart, F, K, k0);
 }
@@ -111,7 +64,7 @@ __device__ __forceinline__ void reduce_and_store(const ACC (&acc)[KC][M * M], AC
 template <int M, int KC, bool UNIT, typename ACC>
 __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ X, const float* __restrict__ R,
                                                      float* __restrict__ wscale, int model, int raw,
-                                                     ACC* __restrict__ Vpart, int T, int F, int K, int tc) {
+                                                     double* __restrict__ Vpart, int T, int F, int K, int tc) {
     constexpr int NA = M * M;
     __shared__ ACC lds[kChunk * kLdsStride];
 
@@ -199,88 +152,6 @@ __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Packed-fp32 arithmetic for two sources on natural (re, im) register pairs.  hipcc's own code for the generic
-// accumulate() spends a third of its VALU instructions on moves that assemble operand pairs (measured in the
-// ISA: 102 v_mov next to 146 v_pk_* per frame); VOP3P's op_sel / op_sel_hi / neg_hi modifiers make them
-// unnecessary: every operand is a pair exactly as ds_read_b128 delivered it.
-//   x_c conj(x_d) = (xr_c xr_d + xi_c xi_d,  xi_c xr_d - xr_c xi_d)
-//     p  = (xr_c * xr_d, -(xr_c * xi_d))            v_pk_mul  src0 lo broadcast, neg_hi on src1
-//     p += (xi_c * xi_d,   xi_c * xr_d)             v_pk_fma  src0 hi broadcast, src1 halves swapped
-//     V_k += w_k * p                                 v_pk_fma  w = (w_0, w_1) pair, lo | hi broadcast
-// ---------------------------------------------------------------------------------------------
-using v2f = __attribute__((ext_vector_type(2))) float;
-
-__device__ __forceinline__ v2f pk_mul_lo_negim(v2f a, v2f b) {          // (a.x * b.x, -(a.x * b.y))
-    v2f r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ v2f pk_fma_hi_swap(v2f a, v2f b, v2f c) {    // (c.x + a.y * b.y, c.y + a.y * b.x)
-    v2f r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ v2f pk_fma_w0(v2f w, v2f p, v2f c) {         // c + w.x * p
-    v2f r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(p), "v"(c));
-    return r;
-}
-__device__ __forceinline__ v2f pk_fma_w1(v2f w, v2f p, v2f c) {         // c + w.y * p
-    v2f r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(w), "v"(p), "v"(c));
-    return r;
-}
-
-// accumulators of TWO sources in that layout: off-diagonal entries as (re, im) pairs, diagonals as scalars
-template <int M>
-struct PkAcc2 {
-    static constexpr int NP = M * (M - 1) / 2;
-    v2f pair[2][NP];
-    float diag[2][M];
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-#pragma unroll
-            for (int i = 0; i < NP; ++i) pair[k][i] = v2f{0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < M; ++c) diag[k][c] = 0.f;
-        }
-    }
-    // x[c] = (re, im) of channel c; w = (w_0, w_1)
-    __device__ __forceinline__ void add(const v2f (&x)[M], v2f w) {
-#pragma unroll
-        for (int c = 0; c < M; ++c) {
-            const v2f sq = x[c] * x[c];
-            const float p = sq.x + sq.y;
-            diag[0][c] = fmaf(w.x, p, diag[0][c]);
-            diag[1][c] = fmaf(w.y, p, diag[1][c]);
-        }
-        // the compiler keeps inline asm in source order and knows no latencies: the products of a whole row are
-        // formed first (independent instructions back to back), then accumulated
-        int i0 = 0;
-#pragma unroll
-        for (int c = 0; c < M; ++c) {
-            v2f p[M];
-#pragma unroll
-            for (int d = c + 1; d < M; ++d) p[d] = pk_mul_lo_negim(x[c], x[d]);
-#pragma unroll
-            for (int d = c + 1; d < M; ++d) p[d] = pk_fma_hi_swap(x[c], x[d], p[d]);
-#pragma unroll
-            for (int d = c + 1; d < M; ++d) pair[0][i0 + d - c - 1] = pk_fma_w0(w, p[d], pair[0][i0 + d - c - 1]);
-#pragma unroll
-            for (int d = c + 1; d < M; ++d) pair[1][i0 + d - c - 1] = pk_fma_w1(w, p[d], pair[1][i0 + d - c - 1]);
-            i0 += M - c - 1;
-        }
-    }
-    // packed Hermitian layout (herm_pair_index): accumulator e = k * M*M + a
-    __device__ __forceinline__ float at(int e) const {
-        const int k = e / (M * M), a = e % (M * M);
-        if (a < M) return diag[k][a];
-        return ((a - M) & 1) ? pair[k][(a - M) >> 1].y : pair[k][(a - M) >> 1].x;
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
 // LDS-DMA variant of the weighted pass (even M).  Same lane geometry and arithmetic as cov_kernel, but
 // X goes HBM -> LDS with global_load_lds (no staging registers) into a private 4-stage ring per wave:
 // three steps (3 * 64 lanes * M*8 bytes) stay in flight while the fourth is consumed, which is what a
@@ -327,7 +198,7 @@ __device__ __forceinline__ void ring_read<2>(unsigned addr, float4 (&v)[2]) {
 template <int M, int KC>
 __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __restrict__ X, const float* __restrict__ R,
                                                             float* __restrict__ wscale, int model, int raw,
-                                                            float* __restrict__ Vpart, int T, int F, int K, int tc) {
+                                                            double* __restrict__ Vpart, int T, int F, int K, int tc) {
     constexpr int NA = M * M;
     constexpr int PIECES = M / 2;                       // 16-byte pieces of one M-vector
     constexpr int STAGE = PIECES * 64;                  // float4 per stage per wave
@@ -454,7 +325,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
 }
 
 template <typename ACC>
-using CovKernel = void (*)(const float2*, const float*, float*, int, int, ACC*, int, int, int, int);
+using CovKernel = void (*)(const float2*, const float*, float*, int, int, double*, int, int, int, int);   // ACC = accumulator type
 
 // (M, KC, unit weights) -> kernel instantiation, handed to fn together with its KC.  Register budget:
 // KC * M^2 accumulators of ACC must stay below ~144 registers.
@@ -530,7 +401,7 @@ hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt,
         });
     return dispatch_cov<float>(M, kc, R == nullptr, [&](CovKernel<float> kern, int KC) {
         return launch_dominant(kern, dim3(g.nbg, g.nsplit, (K + KC - 1) / KC), dim3(kBlock), 0, s, X, R, wscale, model, raw,
-                               static_cast<float*>(Vpart), T, F, K, g.tc);
+                               static_cast<double*>(Vpart), T, F, K, g.tc);
     });
 }
 

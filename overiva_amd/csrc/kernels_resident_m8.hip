@@ -1,0 +1,6 @@
+// X-resident iteration kernel, 8 channels (see resident_kernel.inc)
+#include "resident_kernel.inc"
+
+namespace oiva {
+hipError_t launch_resident_m8(hipStream_t s, const ResidentArgs& a, int K, bool update_f64) { return launch_resident_m<8>(s, a, K, update_f64); }
+}  // namespace oiva

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "oiva_internal.h"
+#include "resident.h"
 
 using namespace oiva;
 
@@ -84,6 +85,10 @@ struct oiva_plan {
     int prec = 0;                 // OIVA_PREC_* bits (oiva_plan_set_precision)
     bool upd_f64() const { return prec & OIVA_PREC_UPDATE_F64; }
     bool cov_f64() const { return prec & OIVA_PREC_COV_F64; }
+    // element type of the covariance partials: the vector-ALU kernels (<= 8 channels) always sum their float32 lane
+    // chains across lanes in float64 and store float64 partials; the 9..16-channel matrix-core kernel stores its
+    // accumulator type
+    bool vpart_f64() const { return cov_f64() || M <= 8; }
     int use_graph = 0;
     // OGIVE (ive.py): per-bin state, allocated by oiva_plan_ogive_begin
     OgiveState og{};
@@ -94,6 +99,21 @@ struct oiva_plan {
     hipGraphExec_t og_graph = nullptr;
     int og_graph_n = 0, og_graph_phase = -1;
     double og_graph_mu = 0., og_graph_tol = 0.;
+    // X-resident iteration (resident.h): geometry, exchange buffers, epoch of the last launch
+    ResidentGeom rg{};
+    bool res_ok = false;           // the shape qualifies
+    bool res_on = false;
+    void* res_block = nullptr;     // one allocation: parts | vpart | rsum | wpub | flags | ctrl | stamps
+    float* res_parts = nullptr;
+    double* res_vpart = nullptr;
+    double* res_rsum = nullptr;
+    float2* res_wpub = nullptr;
+    unsigned* res_flags = nullptr; // flag_p | flag_v | flag_w | ctrl
+    unsigned long long* res_stamps = nullptr;
+    size_t res_sync_bytes = 0;     // flags + ctrl
+    unsigned res_epoch = 0;
+    int res_last_code = 0, res_launches = 0, res_fallbacks = 0, res_stamped = 0;
+    int res_timeout_ms = 0, res_stall = -1;
     hipGraphExec_t graph_exec = nullptr;        // one iteration
     hipGraphExec_t graph_batch_exec = nullptr;  // kGraphBatch iterations
     hipEvent_t ev[2] = {};
@@ -237,7 +257,7 @@ int stage_update(oiva_plan* p, bool init_only) {
     a.What64 = p->upd_f64() ? p->What64 : nullptr;
     a.Cx = p->Cx;
     a.Vpart = p->Vpart;
-    a.vpart_f64 = p->cov_f64() ? 1 : 0;
+    a.vpart_f64 = p->vpart_f64() ? 1 : 0;
     a.wscale = (!init_only && p->wscale_pending) ? p->wscale : nullptr;
     a.nsplit = p->cov.nsplit;
     a.T = p->T;
@@ -259,6 +279,100 @@ int one_iteration(oiva_plan* p) {
     if ((rc = stage_activation(p, p->Ppart, p->pw.nb))) return rc;
     if ((rc = stage_cov(p))) return rc;
     return stage_update(p, false);
+}
+
+// ---- X-resident iteration (resident.h) -------------------------------------------------------------
+constexpr int kResidentStampIters = 256;
+
+bool resident_applies(const oiva_plan* p) {
+    return p->res_on && p->res_ok && p->F == p->F_total && !p->cov_f64() && !p->raw_weights && !p->wscale_pending;
+}
+
+int resident_alloc(oiva_plan* p) {
+    if (p->res_block) return OIVA_OK;
+    const ResidentGeom& g = p->rg;
+    const size_t Fp = (size_t)g.NB * 16, NA = (size_t)p->M * p->M, K = p->K;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_parts = up((size_t)2 * g.NB * g.NS * g.TW * K * sizeof(float));
+    const size_t b_vpart = up(((size_t)g.NS * Fp * K * NA + 2) * sizeof(double));
+    const size_t b_rsum = up((size_t)g.NB * g.NS * K * sizeof(double));
+    const size_t b_wpub = up(Fp * K * p->M * sizeof(float2));
+    const size_t b_flags = up(((size_t)3 * g.NB * g.NS + 16) * sizeof(unsigned));
+    const size_t b_stamps = up((size_t)kResidentStampIters * kResidentStamps * sizeof(unsigned long long));
+    const size_t total = b_parts + b_vpart + b_rsum + b_wpub + b_flags + b_stamps;
+    HIP_TRY(hipMalloc(&p->res_block, total));
+    HIP_TRY(hipMemsetAsync(p->res_block, 0, total, p->stream));
+    char* c = static_cast<char*>(p->res_block);
+    p->res_parts = reinterpret_cast<float*>(c);
+    c += b_parts;
+    p->res_vpart = reinterpret_cast<double*>(c);
+    c += b_vpart;
+    p->res_rsum = reinterpret_cast<double*>(c);
+    c += b_rsum;
+    p->res_wpub = reinterpret_cast<float2*>(c);
+    c += b_wpub;
+    p->res_flags = reinterpret_cast<unsigned*>(c);
+    c += b_flags;
+    p->res_stamps = reinterpret_cast<unsigned long long*>(c);
+    p->res_sync_bytes = b_flags;
+    p->res_epoch = 0;
+    return OIVA_OK;
+}
+
+// n iterations in one persistent launch.  Synchronous.  *ran = false when the launch gave up (nothing changed):
+// the caller then runs the four-launch path.
+int run_resident(oiva_plan* p, int n, bool* ran) {
+    *ran = false;
+    int rc = resident_alloc(p);
+    if (rc) return rc;
+    const ResidentGeom& g = p->rg;
+    const size_t nwg = (size_t)g.NB * g.NS;
+    ResidentArgs a{};
+    a.X = p->X;
+    a.What = p->What;
+    a.What64 = p->upd_f64() ? p->What64 : nullptr;
+    a.what64_valid = p->what64_valid ? 1 : 0;
+    a.Cx = p->Cx;
+    a.parts = p->res_parts;
+    a.vpart = p->res_vpart;
+    a.rsum = p->res_rsum;
+    a.wpub = p->res_wpub;
+    a.flag_p = p->res_flags;
+    a.flag_v = p->res_flags + nwg;
+    a.flag_w = p->res_flags + 2 * nwg;
+    a.ctrl = p->res_flags + 3 * nwg;
+    a.stamps = n <= kResidentStampIters ? p->res_stamps : nullptr;
+    a.T = p->T;
+    a.F = p->F;
+    a.F_total = p->F_total;
+    a.model = p->model;
+    a.g = g;
+    a.n_iter = n;
+    a.epoch0 = p->res_epoch;
+    a.timeout_ticks = (long long)(p->res_timeout_ms > 0 ? p->res_timeout_ms : 2000) * 100000;   // 100 MHz clock
+    a.stall_block = p->res_stall;
+    HIP_TRY(launch_resident(p->stream, a, p->M, p->K, p->upd_f64()));
+    p->res_launches++;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    unsigned code = 0;
+    HIP_TRY(hipMemcpy(&code, a.ctrl, sizeof(code), hipMemcpyDeviceToHost));
+    if (code != 0) {
+        // some wait ran into its time-out (workgroups not co-resident, or the test hook): W_hat was not written back.
+        // Clear the flags, start the epochs over and stay on the four-launch path from here on.
+        HIP_TRY(hipMemset(p->res_flags, 0, p->res_sync_bytes));
+        p->res_epoch = 0;
+        p->res_last_code = (int)code;
+        p->res_fallbacks++;
+        p->res_on = false;
+        p->res_stamped = 0;
+        return OIVA_OK;
+    }
+    p->res_epoch += (unsigned)n;
+    p->res_stamped = a.stamps ? n : 0;
+    p->what64_valid = a.What64 != nullptr;      // the float32 update leaves the complex128 copy behind
+    p->wscale_pending = false;
+    *ran = true;
+    return OIVA_OK;
 }
 
 // Capture (stream capture records, it does not execute) and instantiate the two graphs an iterate() call
@@ -395,6 +509,7 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     choose_cov_geom(p, 0);
     choose_pow_geom(p, 0);
     choose_stats_geom(p);
+    p->res_ok = resident_geometry(T, F, M, K, p->n_cu, &p->rg);
     const size_t nTK = (size_t)T * K;
     const size_t nFMM = (size_t)F * M * M;
     hipError_t e = hipSuccess;
@@ -436,7 +551,7 @@ int oiva_plan_destroy(oiva_plan* p) {
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->graph_batch_exec) (void)hipGraphExecDestroy(p->graph_batch_exec);
     if (p->og_graph) (void)hipGraphExecDestroy(p->og_graph);
-    void* bufs[] = {p->X_owned, p->What, p->What64, p->Cx,        p->Vpart,    p->Ppart, p->Plocal,
+    void* bufs[] = {p->X_owned, p->What, p->What64, p->Cx,        p->Vpart,    p->Ppart, p->Plocal, p->res_block,
                     p->R,       p->wscale, p->Spart, p->Y,      p->scratch_c, p->scratch_p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -524,7 +639,7 @@ int oiva_plan_covariance(oiva_plan* p) {
     g.kc = 1;
     // unit weights, one "source": partials land in Vpart laid out as [nsplit][F][1][M*M]
     HIP_TRY(launch_cov(p->stream, p->X, nullptr, nullptr, nullptr, p->model, 0, p->Vpart, p->cov_f64(), p->T, p->F, p->M, 1, g));
-    HIP_TRY(launch_sum_parts(p->stream, p->Vpart, p->cov_f64(), g.nsplit, p->Cx, (long long)p->F * p->M * p->M, 1. / (double)p->T));
+    HIP_TRY(launch_sum_parts(p->stream, p->Vpart, p->vpart_f64(), g.nsplit, p->Cx, (long long)p->F * p->M * p->M, 1. / (double)p->T));
     p->have_cx = true;
     return OIVA_OK;
 }
@@ -618,6 +733,11 @@ int oiva_plan_iterate(oiva_plan* p, int n) {
          "plan owns a bin shard: drive it with oiva_plan_power / all-gather / oiva_plan_update");
     DeviceGuard guard(p->device);
     if (n == 0) return OIVA_OK;
+    if (resident_applies(p)) {
+        bool ran = false;
+        if ((rc = run_resident(p, n, &ran))) return rc;
+        if (ran) return OIVA_OK;
+    }
     if (p->use_graph) {
         if ((rc = build_graphs(p))) return rc;
         int left = n;
@@ -880,6 +1000,57 @@ int oiva_plan_set_precision(oiva_plan* p, int flags) {
     return OIVA_OK;
 }
 
+// ---- X-resident iteration ------------------------------------------------------------------------------
+int oiva_plan_set_resident(oiva_plan* p, int enable) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    if (!enable) {
+        p->res_on = false;
+        return OIVA_OK;
+    }
+    NEED(p->res_ok, OIVA_ERR_ARG,
+         "shape does not qualify for the X-resident iteration (4 or 8 channels, 1 or 2 sources with background channels, "
+         "16 bins x <= 256 frames per compute unit)");
+    DeviceGuard guard(p->device);
+    int rc = resident_alloc(p);
+    if (rc) return rc;
+    p->res_on = true;
+    return OIVA_OK;
+}
+
+int oiva_plan_resident_info(oiva_plan* p, int* info) {
+    NEED(p && info, OIVA_ERR_ARG, "null argument");
+    const ResidentGeom& g = p->rg;
+    const int v[OIVA_RESIDENT_INFO] = {p->res_ok ? 1 : 0, p->res_on ? 1 : 0, g.NB, g.NS, g.TW, g.J, g.JR, g.lds_bytes,
+                                       p->res_last_code, p->res_launches, p->res_fallbacks, g.J * kBlock * p->M * 8};
+    for (int i = 0; i < OIVA_RESIDENT_INFO; ++i) info[i] = v[i];
+    return OIVA_OK;
+}
+
+int oiva_plan_resident_phases(oiva_plan* p, double* phase_us, int* n_iter) {
+    NEED(p && phase_us && n_iter, OIVA_ERR_ARG, "null argument");
+    for (int i = 0; i < OIVA_RESIDENT_PHASES; ++i) phase_us[i] = 0.;
+    *n_iter = 0;
+    if (!p->res_stamps || p->res_stamped <= 0) return OIVA_OK;
+    DeviceGuard guard(p->device);
+    const int n = p->res_stamped;
+    std::vector<unsigned long long> st((size_t)n * kResidentStamps);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(st.data(), p->res_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    static_assert(OIVA_RESIDENT_PHASES == kResidentStamps - 1, "one phase between consecutive stamps");
+    for (int it = 0; it < n; ++it)
+        for (int i = 0; i < OIVA_RESIDENT_PHASES; ++i)
+            phase_us[i] += (double)(st[(size_t)it * kResidentStamps + i + 1] - st[(size_t)it * kResidentStamps + i]) * 0.01 / n;   // 100 MHz ticks
+    *n_iter = n;
+    return OIVA_OK;
+}
+
+int oiva_plan_resident_debug(oiva_plan* p, int timeout_ms, int stall_block) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    p->res_timeout_ms = timeout_ms;
+    p->res_stall = stall_block;
+    return OIVA_OK;
+}
+
 // ---- OGIVE (reference ive.py:33-256) ----------------------------------------------------------------
 int oiva_plan_ogive_begin(oiva_plan* p, int update_mode, int model) {
     int rc = check_ready(p);
@@ -943,7 +1114,7 @@ int oiva_plan_ogive_iterate(oiva_plan* p, int first_epoch, int n, double step_si
             HIP_TRY(launch_activation(p->stream, p->Ppart, p->pw.nb, p->R, p->T, 1, amodel, p->F));   // ive.py:209-217 (floor + 1/r in the consumer)
             HIP_TRY(launch_cov(p->stream, p->X, p->R, p->Plocal, p->wscale, p->model, /*raw: weights 1 / max(r, eps)*/ 1, p->Vpart,
                                p->cov_f64(), p->T, p->F, p->M, 1, p->cov));                    // ive.py:221-227
-            HIP_TRY(launch_ogive_step(p->stream, p->og, p->Vpart, p->cov_f64(), p->cov.nsplit, p->T, p->F, p->M, step_size,
+            HIP_TRY(launch_ogive_step(p->stream, p->og, p->Vpart, p->vpart_f64(), p->cov.nsplit, p->T, p->F, p->M, step_size,
                                       tol));                                                     // ive.py:228-246
         }
         return OIVA_OK;
@@ -1037,7 +1208,7 @@ int oiva_test_get_v(oiva_plan* p, void* V_host, int f64) {
     DeviceGuard guard(p->device);
     const int F = p->F, M = p->M, K = p->K;
     const long long nfk = (long long)F * K * M * M;
-    HIP_TRY(launch_sum_parts(p->stream, p->Vpart, p->cov_f64(), p->cov.nsplit, p->scratch_p, nfk, 1. / (double)p->T));
+    HIP_TRY(launch_sum_parts(p->stream, p->Vpart, p->vpart_f64(), p->cov.nsplit, p->scratch_p, nfk, 1. / (double)p->T));
     HIP_TRY(launch_unpack_herm(p->stream, p->scratch_p, p->scratch_c, f64 != 0, (long long)F * K, M));
     HIP_TRY(hipStreamSynchronize(p->stream));
     const size_t esz = f64 ? sizeof(double2) : sizeof(float2);

@@ -1,0 +1,56 @@
+// X-resident iteration: declarations shared by plan.hip and the kernels_resident_*.hip translation units.
+#pragma once
+#include "oiva_internal.h"
+
+#include <algorithm>
+
+namespace oiva {
+
+// Geometry of the resident launch: workgroup (g, c) owns bin group g (16 bins) x frame split c (TW frames) of X for
+// the whole launch; lane (b, q) of it owns the M-vector of bin b at the J frames q + 16 j, the first JR of them in
+// registers and the other JL = J - JR in LDS.
+struct ResidentGeom {
+    int NB = 0;        // bin groups of 16
+    int NS = 0;        // frame splits
+    int TW = 0;        // frames per split (multiple of 16, <= 256)
+    int J = 0;         // frames per lane = TW / 16
+    int JR = 0;        // of them in registers (0 or kResidentRegFrames)
+    int lds_bytes = 0;
+};
+constexpr int kResidentRegFrames = 8;
+constexpr int kResidentMaxTW = 256;          // one thread per frame of the split in the activation phase
+constexpr int kResidentLdsXBytes = 128 << 10;   // LDS given to X (of 160 KB; the rest is reduction scratch and tables)
+
+struct ResidentArgs {
+    const float2* X;        // (T, F, M)
+    float2* What;           // (F, M, M) complex64, in/out
+    double2* What64;        // complex128 copy kept by the float64 update (in/out) or nullptr
+    int what64_valid;       // the complex128 copy holds the current state
+    const double* Cx;       // [F][M*M] packed Hermitian, / T
+    // exchange buffers in this GPU's memory; every word of them is accessed with agent-scope atomics only
+    float* parts;           // [2 (epoch parity)][NB][NS * TW][K] partial source powers
+    double* vpart;          // [NS][NB * 16][K][M*M] packed partial covariances
+    double* rsum;           // [NB][NS][K] sum of the activations r over the split's frames
+    float2* wpub;           // [NB * 16][K][M] conj of the demixing vectors, for the power phase
+    unsigned* flag_p;       // [NS][NB]  epoch of the last published parts
+    unsigned* flag_v;       // [NB][NS]  epoch of the last published covariance partials
+    unsigned* flag_w;       // [NB][NS]  epoch of the last published demixing vectors
+    unsigned* ctrl;         // [0] give-up code (0 = fine)
+    unsigned long long* stamps;   // [n_iter][kResidentStamps] 100 MHz timestamps of workgroup 0, or nullptr
+    int T, F, F_total, model;
+    ResidentGeom g;
+    int n_iter;
+    unsigned epoch0;        // epochs epoch0 + 1 ... epoch0 + n_iter
+    long long timeout_ticks;   // 100 MHz ticks a wait may take before the launch gives up
+    int stall_block;        // test hook: this workgroup never publishes (-1: none)
+};
+constexpr int kResidentStamps = 8;
+
+// true when the shape can run resident on a chip of n_cu compute units (fills g)
+bool resident_geometry(int T, int F, int M, int K, int n_cu, ResidentGeom* g);
+hipError_t launch_resident(hipStream_t s, const ResidentArgs& a, int M, int K, bool update_f64);
+// per-shape instantiations (kernels_resident_m4.hip, kernels_resident_m8.hip)
+hipError_t launch_resident_m4(hipStream_t s, const ResidentArgs& a, int K, bool update_f64);
+hipError_t launch_resident_m8(hipStream_t s, const ResidentArgs& a, int K, bool update_f64);
+
+}  // namespace oiva

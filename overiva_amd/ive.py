@@ -78,7 +78,9 @@ def ogive(
     if n_iter < 0:
         raise ValueError("n_iter must be >= 0")
     precision = _ov.get_precision()
-    wdtype = np.complex128 if precision == "precise" else np.complex64
+    if precision == "auto":          # the per-bin gradient step is float64 whatever the mode; OGIVE was validated with the float64 covariance pass
+        precision = "precise"
+    wdtype = np.complex64 if precision == "fast" else np.complex128
     with Plan(n_frames, n_freq, n_chan, 1, model, device=_ov.get_device()) as plan:
         plan.set_precision(precision)
         plan.set_x(X)

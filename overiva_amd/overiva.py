@@ -25,16 +25,27 @@ from . import sharded
 from .plan import DeviceX, Plan
 
 _device = None
-_precision = "precise"
+_precision = "auto"
+MODES = ("auto", "fast", "mixed", "precise")
 
 
 def set_precision(mode):
-    """Arithmetic of subsequent ``overiva()`` / ``auxiva_pca()`` calls in this process: ``"precise"`` (default)
-    or ``"fast"`` (see the module docstring)."""
+    """Arithmetic of subsequent ``overiva()`` / ``auxiva_pca()`` calls in this process: ``"auto"`` (default),
+    ``"fast"``, ``"mixed"`` or ``"precise"`` (see the module docstring)."""
     global _precision
-    if mode not in ("fast", "precise"):
-        raise ValueError("precision must be 'fast' or 'precise'")
+    if mode not in MODES:
+        raise ValueError(f"precision must be one of {MODES}")
     _precision = mode
+
+
+def resolve_precision(dtype, n_chan, mode=None):
+    """``"auto"`` follows the reference, which computes in the dtype of X (overiva.py:89,126,131): complex64 input on
+    up to 8 channels -> ``"mixed"``; complex128 input, or 9..16 channels (whose matrix-core covariance pass keeps
+    float32 partial sums) -> ``"precise"``"""
+    mode = _precision if mode is None else mode
+    if mode != "auto":
+        return mode
+    return "mixed" if np.dtype(dtype) == np.complex64 and n_chan <= 8 else "precise"
 
 
 def get_precision():
@@ -128,7 +139,7 @@ def overiva(
     if n_iter < 0:
         raise ValueError("n_iter must be >= 0")
 
-    precision = _precision
+    precision = resolve_precision(dtype, n_chan)
     group = sharded.active_group()
     if group is not None and isinstance(X, DeviceX):
         raise ValueError("a device-resident X cannot be sharded over ranks: pass the host array")
@@ -179,7 +190,7 @@ class _SingleDevice:
     def __init__(self, T, F, M, K, model, precision="fast"):
         self.plan = Plan(T, F, M, K, model, device=get_device())
         self.plan.set_precision(precision)
-        self.wdtype = np.complex128 if precision == "precise" else np.complex64
+        self.wdtype = np.complex64 if precision == "fast" else np.complex128
         if T * F * M >= self.GRAPH_MIN_ELEMENTS:
             self.plan.use_graph(True)
 

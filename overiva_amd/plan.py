@@ -215,12 +215,39 @@ class Plan:
         _lib.check(self.lib.oiva_plan_use_graph(self.h, 1 if enable else 0))
 
     def set_precision(self, mode="fast", row_layout=False):
-        """``"fast"`` (float32 everywhere), ``"precise"`` (float64 covariance accumulation and per-bin algebra:
-        the reference's complex128 arithmetic on complex64 data), or an int of ``_lib.PREC_*`` bits."""
-        flags = {"fast": _lib.PREC_FAST, "precise": _lib.PREC_PRECISE}[mode] if isinstance(mode, str) else int(mode)
+        """``"fast"`` (float32 products, lane chains and per-bin algebra), ``"mixed"`` (float32 products and lane
+        chains of the covariance pass, float64 sums across lanes / splits and float64 per-bin algebra, W_hat carried in
+        complex128), ``"precise"`` (float64 covariance accumulation on the fp64 matrix cores + float64 algebra: the
+        reference's complex128 arithmetic on complex64 data), or an int of ``_lib.PREC_*`` bits."""
+        flags = _lib.PREC_BY_NAME[mode] if isinstance(mode, str) else int(mode)
         if row_layout:
             flags |= _lib.PREC_UPDATE_ROWS
         _lib.check(self.lib.oiva_plan_set_precision(self.h, flags))
+
+    # -- X-resident iteration (include/overiva_hip.h, csrc/resident_kernel.inc) -------------------
+    RESIDENT_INFO = ("qualifies", "enabled", "bin_groups", "frame_splits", "frames_per_split", "frames_per_lane",
+                     "frames_in_registers", "lds_bytes", "last_give_up_code", "launches", "fallbacks", "x_bytes_per_cu")
+    RESIDENT_PHASES = ("demix_power", "wait_parts", "activation", "weighted_cov", "wait_partials", "ip_update", "wait_w")
+
+    def set_resident(self, enable=True):
+        """the loop body as ONE persistent launch per ``iterate`` call with X held on chip; ValueError when the shape
+        does not qualify"""
+        _lib.check(self.lib.oiva_plan_set_resident(self.h, 1 if enable else 0))
+
+    def resident_info(self):
+        arr = (C.c_int * len(self.RESIDENT_INFO))()
+        _lib.check(self.lib.oiva_plan_resident_info(self.h, arr))
+        return dict(zip(self.RESIDENT_INFO, list(arr)))
+
+    def resident_phases(self):
+        """(microseconds per phase of workgroup 0 averaged over the last resident launch, iterations covered)"""
+        arr = (C.c_double * len(self.RESIDENT_PHASES))()
+        n = C.c_int()
+        _lib.check(self.lib.oiva_plan_resident_phases(self.h, arr, C.byref(n)))
+        return dict(zip(self.RESIDENT_PHASES, list(arr))), n.value
+
+    def resident_debug(self, timeout_ms=0, stall_block=-1):
+        _lib.check(self.lib.oiva_plan_resident_debug(self.h, int(timeout_ms), int(stall_block)))
 
     # -- test-only stage access -----------------------------------------------------------------
     def t_set_rinv(self, rinv):

@@ -63,7 +63,7 @@ class HipEngine:
         self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(device=self.device)
         self.plan = Plan(T, F_local, M, K, model, device=device, F_total=F_total, stream=self.stream.cuda_stream)
         self.plan.set_precision(precision)
-        self.wdtype = np.complex128 if precision == "precise" else np.complex64
+        self.wdtype = np.complex64 if precision == "fast" else np.complex128
         self.T, self.K = T, K
 
     def stream_ctx(self):
@@ -204,7 +204,7 @@ class BinShardedSolver:
         try:
             local, err = self.engine.get_w(), None
         except np.linalg.LinAlgError as e:
-            local, err = np.full((self.f1 - self.f0, self.M, self.K), np.nan, np.complex64), e
+            local, err = np.full((self.f1 - self.f0, self.M, self.K), np.nan, getattr(self.engine, "wdtype", np.complex64)), e
         W = self._gather_bins(local, axis=0)
         if err is not None or not np.all(np.isfinite(W)):
             raise np.linalg.LinAlgError(str(err) if err is not None else
