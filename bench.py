@@ -10,18 +10,28 @@ resident in HBM when it starts.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1 shards the 2048 bins over the ranks (strong scaling: the problem is fixed) with one RCCL
-all-gather of the (T, K) partial source powers per iteration.
+all-gather of the (T, K) partial source powers per iteration.  Started WITHOUT a launcher (no
+WORLD_SIZE in the environment) `--gpus N` starts its N ranks itself, as child processes, before this
+process has touched a GPU, and relays rank 0's line; a host watchdog ends a run that does not finish
+(a dead peer, a transport that does not work on this node) instead of hanging, and an attempt with
+the opt-in push exchange that fails is repeated, in fresh processes, with the collective.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- weighted-covariance pass: algorithmic bytes (8TFM + 4TK + 8FKM^2) /
                   average kernel duration measured with HIP events on the kernel's own stream
   cpu_baseline -- the oracle's reference-faithful NumPy restatement of overiva.py timed on this
-                  box's host cores on a bounded sample (N = 1 only)
+                  box's host cores on the full workload (N = 1 only)
+  other_modes  -- the other arithmetic modes on the same workload, same protocol
+  configs      -- (N = 1) BASELINE configs[1], configs[4] and one rank's shard of configs[3], measured in
+                  the same process after the headline
 """
 import argparse
 import json
 import os
+import signal
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,14 +41,24 @@ sys.path.insert(0, REPO)
 
 MODEL = "laplace"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
-# --config: the headline workload (default; the one BASELINE.json's metric is quoted on) and configs[4]
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (= the fp32 vector peak)
+# --config: the headline workload (default; the one BASELINE.json's metric is quoted on) and the other shapes
 CONFIGS = {
     "headline": dict(T=4000, F=2048, M=8, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[2])"),
     "cfg5": dict(T=4000, F=2048, M=16, K=16, name="determined AuxIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[4])"),
+    "cfg2": dict(T=1000, F=513, M=4, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[1])"),
+    "shard8": dict(T=4000, F=256, M=8, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64: one rank's shard of the headline shape at 8 GPUs (BASELINE.json configs[3])"),
 }
 T, F, M, K = 4000, 2048, 8, 2
 WORKLOAD = CONFIGS["headline"]["name"].format(T=T, F=F, M=M, K=K)
+MODES = ("fast", "mixed", "precise")
+MODE_TEXT = {
+    "fast": "fast (float32 products, lane chains and per-bin algebra; float64 sums across lanes and frame splits)",
+    "mixed": "mixed (float32 products and lane chains of the covariance pass, float64 sums across lanes / splits, float64 per-bin "
+             "algebra with W_hat in complex128: what overiva() runs for complex64 input on <= 8 channels)",
+    "precise": "precise (float64 covariance accumulation on the fp64 matrix cores + float64 per-bin algebra: what overiva() runs "
+               "for complex128 input and for 9..16 channels)",
+}
 
 
 def select_config(name):
@@ -56,9 +76,9 @@ def cov_algorithmic_bytes(t, f, m, k):
 def measured_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same workload
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction; see
-    profiles/r01_pmc_hbm_traffic.json).  PMC counters need rocprofv3 around the process, so they cannot
+    profiles/r03_pmc_hbm_traffic.json).  PMC counters need rocprofv3 around the process, so they cannot
     be sampled from inside a plain bench run; None when the profile is absent."""
-    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         path = os.path.join(REPO, "profiles", name)
         try:
             with open(path) as f:
@@ -68,12 +88,13 @@ def measured_traffic(kernel_key):
     return None, None
 
 
-def synth_x_device(torch, device, f0, f1):
+def synth_x_device(torch, device, f0, f1, shape=None):
     """The iid complex64 workload, generated on the device (seeded per bin so that any sharding of
     the bins sees the same tensor)."""
+    t, f, m = shape or (T, F, M)
     g = torch.Generator(device=device)
     g.manual_seed(1234)
-    x = torch.randn((T, F, M, 2), generator=g, device=device, dtype=torch.float32)
+    x = torch.randn((t, f, m, 2), generator=g, device=device, dtype=torch.float32)
     x = x[:, f0:f1].contiguous()
     return torch.view_as_complex(x)
 
@@ -89,61 +110,61 @@ def _cpu_model():
     return "unknown"
 
 
-def _time_oracle(fs):
-    """seconds per iteration of the reference-faithful oracle on `fs` bins: (t(5 its) - t(1 it)) / 4, so the
-    prologue (input covariance, allocation) cancels; best of two after a warm-up call"""
+def _time_oracle(X):
+    """seconds per iteration of the reference-faithful oracle: (t(4 its) - t(1 it)) / 3, so the prologue (input
+    covariance, allocation) cancels; after a warm-up call"""
     from oracle import overiva_oracle as orc
 
-    X = orc.synth_iid(T, fs, M, seed=0)
     orc.overiva_faithful(X, n_src=K, n_iter=1, proj_back=False, model=MODEL)      # warm-up (page faults, BLAS threads)
-    best = None
-    for _ in range(2):
-        t0 = time.perf_counter()
-        orc.overiva_faithful(X, n_src=K, n_iter=1, proj_back=False, model=MODEL)
-        t1 = time.perf_counter()
-        orc.overiva_faithful(X, n_src=K, n_iter=5, proj_back=False, model=MODEL)
-        t2 = time.perf_counter()
-        per = ((t2 - t1) - (t1 - t0)) / 4.0
-        best = per if best is None else min(best, per)
-    return max(best, 1e-6)
+    t0 = time.perf_counter()
+    orc.overiva_faithful(X, n_src=K, n_iter=1, proj_back=False, model=MODEL)
+    t1 = time.perf_counter()
+    orc.overiva_faithful(X, n_src=K, n_iter=4, proj_back=False, model=MODEL)
+    t2 = time.perf_counter()
+    return max(((t2 - t1) - (t1 - t0)) / 3.0, 1e-6)
 
 
 def cpu_baseline():
-    """Reference-faithful NumPy restatement (oracle) on a bounded sample: 1024 of the 2048 bins, all 4000
-    frames, 8 mics / 2 src (about 15 s of CPU work); work is linear in bins, so it/s at 2048 bins = it/s on the sample
-    * 1024 / 2048.
-    Timed with the default BLAS threading and, as the reference's own sweep pinned BLAS to one thread
-    (overiva_sim.py:85-91), once more on a smaller sample with one thread."""
-    fs = 1024
-    per_iter = _time_oracle(fs)
-    threads = os.cpu_count()
-    one = None
+    """Reference-faithful NumPy restatement (oracle/overiva_oracle.py::overiva_faithful: same statements, temporaries and
+    dtypes as overiva.py:80-204; profiles/r03_cpu_side_by_side.json shows it next to the real reference in the build
+    container) on the FULL workload -- all 2048 bins x 4000 frames x 8 mics / 2 src, about 10 s of CPU work per threading --
+    with the BLAS threading the process starts with (`cores` = the threads threadpoolctl reports for that pool) and, as the
+    reference's own sweep pinned BLAS to one thread (overiva_sim.py:85-91), once more with one thread."""
+    from oracle import overiva_oracle as orc
+
+    X = orc.synth_iid(T, F, M, seed=0)
+    per_iter = _time_oracle(X)
+    threads, pools, one = os.cpu_count(), None, None
     try:
         from threadpoolctl import threadpool_info, threadpool_limits
 
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
-        fs1 = fs        # same sample: a smaller one would sit in cache and flatter the CPU
+        info = threadpool_info()
+        pools = [{k: i.get(k) for k in ("internal_api", "num_threads", "version")} for i in info]
+        blas = [i.get("num_threads", 1) for i in info if i.get("user_api") == "blas"]
+        threads = max(blas or [i.get("num_threads", 1) for i in info] or [1])
         with threadpool_limits(limits=1):
-            per1 = _time_oracle(fs1)
-        one = {"value": (1.0 / per1) * fs1 / F, "cores": 1,
-               "sample": f"{fs1} of {F} bins, one BLAS thread, {per1:.3f} s per iteration on the sample"}
+            per1 = _time_oracle(X)
+        one = {"value": 1.0 / per1, "cores": 1, "sample": f"the same workload with one BLAS thread, {per1:.3f} s per iteration"}
     except Exception:
         pass
-    # `cores` = the threads that actually did the work: the batched (M x T)(T x M) products of overiva.py:179 do not
-    # thread in OpenBLAS (one thread gives the same rate, see single_thread), so however many BLAS threads the run is
-    # allowed (blas_threads_allowed) it is one core
-    effective = 1 if one and one["value"] > 0.8 * (1.0 / per_iter) * fs / F else threads
-    return {"value": (1.0 / per_iter) * fs / F, "unit": "iterations/s", "cores": effective, "kind": "port",
-            "blas_threads_allowed": threads,
-            "cpu": _cpu_model(), "host_cpus": os.cpu_count(), "single_thread": one,
-            "sample": f"oracle.overiva_faithful (NumPy, complex64 in / float64 r like overiva.py) on {fs} of {F} bins x "
-                      f"{T} frames x {M} mics / {K} src, iterations 2-5, scaled by {fs}/{F}; "
-                      f"{per_iter:.3f} s per iteration on the sample"}
+    return {"value": 1.0 / per_iter, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "threadpools": pools, "cpu": _cpu_model(), "host_cpus": os.cpu_count(), "single_thread": one,
+            "note": "the batched (M x T)(T x M) products of overiva.py:179 hardly thread in OpenBLAS: compare single_thread",
+            "sample": f"oracle.overiva_faithful (NumPy, complex64 in / float64 r like overiva.py) on the full {F} bins x "
+                      f"{T} frames x {M} mics / {K} src, iterations 2-4 of a 4-iteration call minus a 1-iteration call; "
+                      f"{per_iter:.3f} s per iteration"}
 
 
-def _time_plan(plan, args):
-    """W untimed warm-up iterations, then exactly K timed ones bracketed by synchronisation; then the same K again
-    with every kernel bracketed by HIP events on the plan's stream"""
+def _median(v):
+    v = sorted(v)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
+def _time_plan(plan, args, repeats=0):
+    """W untimed warm-up iterations, then exactly K timed ones bracketed by synchronisation (the contract measurement);
+    then `repeats` more measurements of the same K iterations (for the median); then the same K again with every kernel
+    bracketed by HIP events on the plan's stream"""
     import torch
 
     plan.iterate(args.warmup)
@@ -154,8 +175,94 @@ def _time_plan(plan, args):
     plan.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    more = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        plan.iterate(args.steps)
+        plan.sync()
+        torch.cuda.synchronize()
+        more.append(time.perf_counter() - t0)
     total_ms, stages = plan.iterate_timed(args.steps, per_kernel=True)
-    return dt, total_ms, stages
+    return dt, total_ms, stages, more
+
+
+def _make_plan(oa, X, shape, mode, graph, resident=False):
+    t, f, m, k = shape
+    plan = oa.Plan(t, f, m, k, MODEL, device=0)
+    plan.set_precision(mode)
+    plan.set_x_device(X.data_ptr(), keepalive=X)
+    plan.covariance()
+    plan.set_w(None)
+    if resident:
+        plan.set_resident(True)
+    elif graph:
+        plan.use_graph(True)
+    return plan
+
+
+def _cov_roofline(shape, mode, cov_ms):
+    t, f, m, k = shape
+    if m <= 8:
+        bytes_cov = cov_algorithmic_bytes(t, f, m, k)
+        achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
+        kname = f"cov_gram_kernel<{min(k, 2)}>" if mode == "precise" else f"cov_dma_kernel<{m}, {min(k, 2)}>"
+        return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, overiva.py:179)",
+                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms}
+    naive = 8.0 * k * m * m * t * f            # complex MACs counted as 8 real flops
+    issued = 6.0 * k * m * m * t * f           # what the planar form issues: 3 MFMAs of 16x16x4 per 4 frames and source
+    kname = "cov_mfma16_kernel<double, 16>" if mode == "precise" else "cov_mfma16_kernel<float, 16>"
+    return kname, {"bound": "mfma", "kernel": f"{kname} (planar v_mfma_f32_16x16x4_f32, overiva.py:179)",
+                   "achieved": issued / (cov_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": issued / (cov_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                   "issued_flops_per_launch": issued, "naive_complex_flops_per_launch": naive,
+                   "naive_complex_tflops": naive / (cov_ms * 1e-3) / 1e12, "avg_launch_ms": cov_ms,
+                   "note": "achieved/frac count ISSUED matrix-core flops; the naive-complex figure is algorithmic speed only"}
+
+
+def _secondary_config(torch, oa, dev, name, args):
+    """one of the other BASELINE configs, same protocol as the headline: the four-launch path (graph replay) and, where the
+    shape qualifies, the X-resident kernel; the faster one is `value`"""
+    c = CONFIGS[name]
+    shape = (c["T"], c["F"], c["M"], c["K"])
+    mode = "mixed" if c["M"] <= 8 else args.cfg5_precision
+    X = synth_x_device(torch, dev, 0, c["F"], shape[:3])
+    torch.cuda.synchronize()
+    out = {"workload": c["name"].format(**c), "precision": mode, "steps": args.steps, "warmup": args.warmup}
+    plan = _make_plan(oa, X, shape, mode, True)
+    dt, total_ms, stages, _ = _time_plan(plan, args)
+    info = plan.resident_info()
+    plan.close()
+    cov_ms = stages["weighted_cov"] / args.steps
+    _, roof = _cov_roofline(shape, mode, cov_ms)
+    if name == "cfg2":
+        roof["note"] = "16 MB of X: resident in L2 / Infinity Cache, the pass is launch- and latency-bound, not a roofline claim"
+    out["four_launch"] = {"value": args.steps / dt, "unit": "iterations/s", "ms_per_step": dt / args.steps * 1e3,
+                          "stage_ms_per_step": {k: v / args.steps for k, v in stages.items()}, "roofline": roof}
+    out["value"], out["path"] = args.steps / dt, "four launches per iteration (hipGraph replay)"
+    if info["qualifies"]:
+        plan = _make_plan(oa, X, shape, mode, False, resident=True)
+        plan.iterate(args.warmup)
+        plan.sync()
+        t0 = time.perf_counter()
+        plan.iterate(args.steps)          # ONE persistent launch
+        plan.sync()
+        dtr = time.perf_counter() - t0
+        phases, nit = plan.resident_phases()
+        info = plan.resident_info()
+        plan.close()
+        out["resident"] = {"value": args.steps / dtr, "unit": "iterations/s", "ms_per_step": dtr / args.steps * 1e3,
+                           "phase_us_workgroup0": phases, "grid": [info["bin_groups"], info["frame_splits"]],
+                           "frames_per_lane": info["frames_per_lane"], "frames_in_registers": info["frames_in_registers"],
+                           "lds_bytes": info["lds_bytes"], "x_bytes_per_cu": info["x_bytes_per_cu"], "fallbacks": info["fallbacks"],
+                           "roofline": {"bound": "latency", "frac": None,
+                                        "note": "X stays in registers + LDS for the whole launch: per iteration the kernel moves only the "
+                                                "exchange words (parts, partial covariances, demixing vectors) through L2; what bounds it "
+                                                "is the dependency chain power -> r -> V -> W across workgroups (phase_us_workgroup0)"}}
+        if info["fallbacks"] == 0 and dtr < dt:
+            out["value"], out["path"] = args.steps / dtr, "X-resident persistent launch (one launch for all the timed iterations)"
+    out["unit"] = "iterations/s"
+    return out
 
 
 def run_single(args):
@@ -165,70 +272,79 @@ def run_single(args):
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    shape = (T, F, M, K)
     X = synth_x_device(torch, dev, 0, F)
     torch.cuda.synchronize()
 
-    def make(mode):
-        plan = oa.Plan(T, F, M, K, MODEL, device=0)
-        plan.set_precision(mode)
-        plan.set_x_device(X.data_ptr(), keepalive=X)
-        plan.covariance()
-        plan.set_w(None)
-        if args.graph:
-            plan.use_graph(True)
-        return plan
-
-    other_mode = None
+    other_modes = []
     if not args.no_other_mode:
-        # the other arithmetic mode on the same workload, same timing protocol (reported next to the metric; the
-        # drop-in overiva() defaults to "precise", the metric's float32 tolerance is met by "fast" on this input).
-        # Measured before the metric's own mode: a process's first tens of milliseconds of GPU work run 2-3 % slower
-        # (clock ramp), and that should not land in `value`.
-        other = "precise" if args.precision == "fast" else "fast"
-        plan = make(other)
-        dt2, total2, stages2 = _time_plan(plan, args)
-        plan.close()
-        other_mode = {"precision": other, "value": args.steps / dt2, "unit": "iterations/s", "ms_per_step": dt2 / args.steps * 1e3,
-                      "stage_ms_per_step": {k: v / args.steps for k, v in stages2.items()}}
-    plan = make(args.precision)
-    dt, total_ms, stages = _time_plan(plan, args)
+        # the other arithmetic modes on the same workload, same timing protocol.  Measured before the metric's own mode:
+        # a process's first tens of milliseconds of GPU work run 2-3 % slower (clock ramp), and that should not land in
+        # `value`.
+        for other in MODES:
+            if other == args.precision:
+                continue
+            plan = _make_plan(oa, X, shape, other, args.graph)
+            dt2, total2, stages2, _ = _time_plan(plan, args)
+            plan.close()
+            cov2 = stages2["weighted_cov"] / args.steps
+            _, roof2 = _cov_roofline(shape, other, cov2)
+            other_modes.append({"precision": other, "value": args.steps / dt2, "unit": "iterations/s", "ms_per_step": dt2 / args.steps * 1e3,
+                                "stage_ms_per_step": {k: v / args.steps for k, v in stages2.items()},
+                                "roofline": {k: roof2[k] for k in ("bound", "kernel", "achieved", "unit", "frac")}})
+    plan = _make_plan(oa, X, shape, args.precision, args.graph)
+    dt, total_ms, stages, more = _time_plan(plan, args, repeats=args.repeats)
     W = plan.get_w()
     assert np.all(np.isfinite(W))
     splits = plan.cov_splits()
     plan.close()
     cov_ms = stages["weighted_cov"] / args.steps
     per_step = {k: v / args.steps for k, v in stages.items()}
+    kname, roofline = _cov_roofline(shape, args.precision, cov_ms)
     if M <= 8:
-        bytes_cov = cov_algorithmic_bytes(T, F, M, K)
-        achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
-        kname = f"cov_dma_kernel<{M}, {min(K, 2)}>" if args.precision == "fast" else f"cov_gram_kernel<{min(K, 2)}>"
         traffic, traffic_src = measured_traffic(kname)
-        roofline = {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, overiva.py:179)",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_cov}
+        roofline.update({"traffic": traffic, "traffic_source": traffic_src})
         # the whole iteration against the same roofline: X is read twice (demix/power pass, covariance pass)
-        bytes_iter = bytes_cov + 8 * T * F * M + 4 * T * K * (1 + F // 64)
+        bytes_iter = roofline["algorithmic_bytes_per_launch"] + 8 * T * F * M + 4 * T * K * (1 + F // 64)
         roofline["iteration"] = {"algorithmic_bytes": bytes_iter, "achieved": bytes_iter / (total_ms / args.steps * 1e-3) / 1e9,
                                  "frac": bytes_iter / (total_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    else:
-        naive = 8.0 * K * M * M * T * F            # complex MACs counted as 8 real flops
-        issued = 6.0 * K * M * M * T * F           # what the planar form issues: 3 MFMAs of 16x16x4 per 4 frames and source
-        roofline = {"bound": "fp32-mfma", "kernel": "cov_mfma16_kernel<float, 16> (planar v_mfma_f32_16x16x4_f32, overiva.py:179)",
-                    "achieved": issued / (cov_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": issued / (cov_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                    "issued_flops_per_launch": issued, "naive_complex_flops_per_launch": naive,
-                    "naive_complex_tflops": naive / (cov_ms * 1e-3) / 1e12,
-                    "note": "achieved/frac count ISSUED matrix-core flops; the naive-complex figure is algorithmic speed only"}
-    roofline.update({"avg_launch_ms": cov_ms, "stage_ms_per_step": per_step, "event_timed_ms_per_step": total_ms / args.steps,
-                     "cov_splits": splits})
+    roofline.update({"stage_ms_per_step": per_step, "event_timed_ms_per_step": total_ms / args.steps, "cov_splits": splits})
     out = result_line(args, 1, dt)
+    if more:
+        rates = [args.steps / d for d in [dt] + more]
+        out["value_median"], out["repeats"] = _median(rates), len(rates)
+        out["value_min"], out["value_max"] = min(rates), max(rates)
     out["roofline"] = roofline
-    if other_mode is not None:
-        out["other_mode"] = other_mode
+    if other_modes:
+        out["other_modes"] = other_modes
+    del X
+    torch.cuda.empty_cache()
+    if not args.no_configs and args.config == "headline":
+        out["configs"] = {}
+        for name in ("cfg2", "shard8", "cfg5"):
+            try:
+                out["configs"][name] = _secondary_config(torch, oa, dev, name, args)
+            except Exception as e:  # a secondary shape must not cost the headline line
+                out["configs"][name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
     out["cpu_baseline"] = cpu_baseline() if not args.no_cpu else None
     if out["cpu_baseline"]:
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     return out
+
+
+def _watchdog(seconds, what):
+    """a run that does not finish (a rank waiting for a dead peer inside a collective, a stream wait that is never
+    satisfied) must end with a non-zero exit code, not hang: the timer thread ends the process"""
+    def fire():
+        sys.stderr.write(f"[bench] watchdog: {what} did not finish within {seconds} s; exiting with code 3\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def run_sharded(args):
@@ -243,6 +359,7 @@ def run_sharded(args):
     world = int(os.environ.setdefault("WORLD_SIZE", "1"))
     local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dog = _watchdog(args.launch_timeout, f"rank {rank} of the sharded run")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if args.backend == "nccl":
@@ -263,8 +380,8 @@ def run_sharded(args):
         p_local = eng.exchange_buffer(ppr)
         p_all = eng.new_gather_buffer(world)
 
-        # transport of the per-iteration all-gather: RCCL through torch.distributed, or the library's push exchange
-        # (validated against the collective on every rank before it is used, else it falls back; exchange.py)
+        # transport of the per-iteration all-gather: RCCL through torch.distributed (default), or the library's push
+        # exchange (opt-in; validated -- including a stream wait that really blocks -- before it is used, exchange.py)
         from overiva_amd.exchange import make_exchange
 
         xchg = make_exchange(eng, dist, None, rank, world, p_local, p_all, prefer=args.exchange)
@@ -334,7 +451,7 @@ def run_sharded(args):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     W = eng.get_w()
     assert np.all(np.isfinite(W))
-    exchange_name = xchg.name
+    exchange_name, exchange_fallback = xchg.name, getattr(xchg, "fallback_reason", None)
     xchg.close()
     eng.close()
     gathered = [None] * world
@@ -342,23 +459,17 @@ def run_sharded(args):
     out = result_line(args, world, float(tmax.item()))
     out["config"]["graph"] = graph is not None
     fl = f1 - f0
-    if M <= 8:
-        bytes_cov = cov_algorithmic_bytes(T, fl, M, K)
-        out["roofline"] = {"bound": "hbm", "kernel": f"cov_dma_kernel<{M}, {min(K, 2)}> on rank 0's {fl} bins",
-                           "achieved": bytes_cov / (cov_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": bytes_cov / (cov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                           "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms, "per": "GPU"}
-    else:
-        issued = 6.0 * K * M * M * T * fl
-        out["roofline"] = {"bound": "fp32-mfma", "kernel": f"cov_mfma16_kernel on rank 0's {fl} bins",
-                           "achieved": issued / (cov_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": issued / (cov_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                           "avg_launch_ms": cov_ms, "per": "GPU"}
+    _, roof = _cov_roofline((T, fl, M, K), args.precision, cov_ms)
+    roof["kernel"] += f" on rank 0's {fl} bins"
+    roof["per"] = "GPU"
+    roof.setdefault("traffic", None)
+    out["roofline"] = roof
     out["cpu_baseline"] = None      # reported at N = 1 only
     out["ranks"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "exchange": exchange_name,
-                    "per_rank_stage_ms": gathered,
-                    "message_bytes_per_rank": int(p_local.numel() * 4)}
+                    "exchange_requested": args.exchange, "fallback": exchange_fallback,
+                    "per_rank_stage_ms": gathered, "message_bytes_per_rank": int(p_local.numel() * 4)}
     dist.destroy_process_group()
+    dog.cancel()
     return out if rank == 0 else None
 
 
@@ -374,14 +485,108 @@ def result_line(args, n_gpus, seconds):
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fast" else "f64",
+        # the arithmetic type of the streaming passes' products and lane chains ("precise": float64 throughout)
+        "dtype": "f64" if args.precision == "precise" else "f32",
         "data": "synthetic",
         "config": {"workload": WORKLOAD, "bins": F, "frames": T, "mics": M, "sources": K, "model": MODEL,
-                   "precision": args.precision + (" (float32 everywhere; overiva() defaults to 'precise', see other_mode)"
-                                                  if args.precision == "fast" else " (float64 covariance accumulation + per-bin algebra)"),
+                   "precision": MODE_TEXT[args.precision],
                    "parallelism": f"bins sharded over {n_gpus} GPU(s), one RCCL all-gather of (T,K) f32 per iteration"
                    if n_gpus > 1 else "single GPU", "graph": bool(args.graph)},
     }
+
+
+# ---- `--gpus N` without a launcher ------------------------------------------------------------------------------
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _strip_option(argv, name):
+    """argv without `name VALUE` / `name=VALUE`"""
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a == name:
+            skip = True
+            continue
+        if a.startswith(name + "="):
+            continue
+        out.append(a)
+    return out
+
+
+def _stop_children(p):
+    """end a launcher child and the ranks it started -- torch.distributed.run puts every rank into a session of its own, so
+    the process group of the launcher does not reach them: SIGTERM to the launcher (its agent then stops its workers),
+    and after a grace period SIGKILL to exactly the processes that descend from it.  Returns what it had written."""
+    kids = []
+    try:
+        import psutil
+
+        kids = psutil.Process(p.pid).children(recursive=True)
+    except Exception:
+        pass
+    p.terminate()
+    try:
+        out, _ = p.communicate(timeout=15)
+    except subprocess.TimeoutExpired:
+        out = None
+    for k in kids:
+        try:
+            k.kill()
+        except Exception:
+            pass
+    if p.poll() is None:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)      # exactly the process group started by launch_ranks
+        except ProcessLookupError:
+            pass
+    if out is None:
+        try:
+            out, _ = p.communicate(timeout=10)
+        except subprocess.TimeoutExpired:
+            out = ""
+    return out
+
+
+def launch_ranks(args, argv, script=None):
+    """Start the N ranks as children (python -m torch.distributed.run) and relay rank 0's JSON line.  Runs before this
+    process has made any GPU call; never replaces this process.  Every attempt is bounded by --launch-timeout: on expiry the
+    children's process group is killed.  An attempt with the push exchange that fails or times out is repeated with the
+    collective, in fresh processes."""
+    attempts = []
+    exchanges = [args.exchange] + (["collective"] if args.exchange != "collective" else [])
+    base = _strip_option(argv, "--exchange")
+    for ex in exchanges:
+        port = _free_port()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + base + ["--exchange", ex]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver supports dmabuf IPC only (RCCL, the push exchange)
+        t0 = time.perf_counter()
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True, start_new_session=True)
+        status = "ok"
+        try:
+            out, _ = p.communicate(timeout=args.launch_timeout + args.launch_grace)     # the ranks' own watchdogs fire first
+        except subprocess.TimeoutExpired:
+            status = "timeout"
+            out = _stop_children(p)
+        lines = [l for l in (out or "").splitlines() if l.startswith("{")]
+        rec = {"exchange": ex, "status": status, "returncode": p.returncode, "seconds": round(time.perf_counter() - t0, 1)}
+        attempts.append(rec)
+        if status == "ok" and p.returncode == 0 and lines:
+            d = json.loads(lines[-1])
+            d["launcher"] = {"spawned_ranks": args.gpus, "attempts": attempts}
+            print(json.dumps(d), flush=True)
+            return 0
+        sys.stderr.write(f"[bench] attempt with exchange={ex} failed: {rec}\n")
+    sys.stderr.write(f"[bench] no attempt produced a result: {attempts}\n")
+    return 1
 
 
 def main():
@@ -392,22 +597,38 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="0: eager; 1 (default): hipGraph replay on a single GPU, eager when sharded; 2: graph also when sharded")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary configs (cfg2, shard8, cfg5) of the N = 1 line")
+    ap.add_argument("--repeats", type=int, default=4, help="extra measurements of the same K steps for value_median (N = 1)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="headline",
-                    help="headline: BASELINE.json configs[2] (the metric's workload); cfg5: configs[4], 16 mics / 16 sources")
-    ap.add_argument("--precision", choices=["fast", "precise"], default="fast",
-                    help="arithmetic of the timed run (default fast = float32, the metric's dtype); the other mode is timed too")
-    ap.add_argument("--no-other-mode", action="store_true", help="do not also time the other arithmetic mode")
+                    help="headline: BASELINE.json configs[2] (the metric's workload); cfg5: configs[4], 16 mics / 16 sources; "
+                         "cfg2: configs[1]; shard8: one rank's shard of configs[3]")
+    ap.add_argument("--precision", choices=list(MODES), default=None,
+                    help="arithmetic of the timed run (default: what overiva() runs on this input -- mixed up to 8 channels, "
+                         "precise for 9..16); the other modes are timed too")
+    ap.add_argument("--cfg5-precision", choices=list(MODES), default="fast",
+                    help="arithmetic of the configs[4] entry of the N = 1 line (overiva() runs it in precise; fast is the "
+                         "float32 matrix-core form the roofline of that shape is about)")
+    ap.add_argument("--no-other-mode", action="store_true", help="do not also time the other arithmetic modes")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (exercises RCCL + graph capture on 1 GPU)")
-    ap.add_argument("--exchange", choices=["collective", "push"], default=os.environ.get("OIVA_EXCHANGE", "push"),
-                    help="all-gather of the partial powers when sharded: the library's push exchange (default; validated against "
-                         "the collective at start-up, falls back to it) or torch.distributed's collective (RCCL)")
+    ap.add_argument("--exchange", choices=["collective", "push"], default=os.environ.get("OIVA_EXCHANGE", "collective"),
+                    help="all-gather of the partial powers when sharded: torch.distributed's collective (RCCL, default) or the "
+                         "library's push exchange (opt-in; validated at start-up, falls back to the collective)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the sharded path (nccl = RCCL; tests use gloo)")
     ap.add_argument("--single-device", action="store_true",
                     help="tests on a 1-GPU box: every rank uses GPU 0 (needs --backend gloo: RCCL refuses two ranks on one device)")
+    ap.add_argument("--launch-timeout", type=int, default=600,
+                    help="seconds a sharded run may take before its watchdog ends it with a non-zero exit code")
+    ap.add_argument("--launch-grace", type=int, default=60, help=argparse.SUPPRESS)
     args = ap.parse_args()
     select_config(args.config)
-    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_sharded:
+    if args.precision is None:
+        args.precision = "mixed" if M <= 8 else "precise"
+    world_env = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and world_env == 0:
+        # no launcher around us: be one.  Nothing above touched a GPU (no torch import, no HIP call).
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if args.gpus > 1 or world_env > 1 or args.force_sharded:
         out = run_sharded(args)
     else:
         out = run_single(args)

@@ -154,6 +154,8 @@ int oiva_plan_demix_c128(oiva_plan *p, void *Y_host, long long row_pitch_bytes, 
  *   wait     : `stream` waits until all `world` parts of this epoch are in this rank's buffer
  *   gathered : the buffer to read after wait (world parts of the padded part size, rank order)
  *   poll     : host-side check with a time-out (used to validate the transport before relying on it)
+ *   force    : host store of the value a stream wait of this epoch waits for -- releases a stream whose wait would
+ *              never be satisfied (a validation that failed); the exchange must not be used afterwards
  */
 #define OIVA_XCHG_MAX_RANKS 16
 #define OIVA_XCHG_HANDLE_BYTES 64
@@ -165,6 +167,7 @@ int oiva_xchg_push(oiva_xchg *x, void *stream, const void *part_dev, long long p
 int oiva_xchg_wait(oiva_xchg *x, void *stream, int epoch);
 int oiva_xchg_gathered(oiva_xchg *x, int epoch, void **gathered);
 int oiva_xchg_poll(oiva_xchg *x, int epoch, int timeout_ms, int *arrived);
+int oiva_xchg_force(oiva_xchg *x, int epoch);
 int oiva_xchg_destroy(oiva_xchg *x);
 
 /*
@@ -224,14 +227,15 @@ int oiva_plan_set_precision(oiva_plan *p, int flags);
  *                              [10] fall-backs so far, [11] the frames of X each compute unit holds, in bytes
  *   oiva_plan_resident_phases: average duration in microseconds, over the iterations of the last resident launch
  *                              (at most 256), of the phases of workgroup 0, from the 100 MHz clock read inside the
- *                              kernel: [0] demix + power, [1] wait for the column's parts, [2] activation,
- *                              [3] covariance, [4] wait for the row's partials, [5] per-bin update, [6] wait for the
- *                              row's demixing vectors; *n_iter = iterations covered (0: nothing recorded)
+ *                              kernel: [0] demix + power, [1] the column's parts (wait + ordered sum), [2] activation,
+ *                              [3] weighted covariance: accumulation, [4] its reduction over the frame phases + publication,
+ *                              [5] wait for the row's partials, [6] per-bin update chain, [7] wait for the row's
+ *                              demixing vectors; *n_iter = iterations covered (0: nothing recorded)
  *   oiva_plan_resident_debug : test hooks -- time-out of a wait in milliseconds (0: default 2000), and the index of a
  *                              workgroup that never publishes (-1: none), which makes the launch give up
  */
 #define OIVA_RESIDENT_INFO 12
-#define OIVA_RESIDENT_PHASES 7
+#define OIVA_RESIDENT_PHASES 8
 int oiva_plan_set_resident(oiva_plan *p, int enable);
 int oiva_plan_resident_info(oiva_plan *p, int *info /* OIVA_RESIDENT_INFO ints */);
 int oiva_plan_resident_phases(oiva_plan *p, double *phase_us /* OIVA_RESIDENT_PHASES */, int *n_iter);

@@ -10,9 +10,9 @@ no CPU fallback: without the built library the calls raise ``HipLibraryMissing``
 from ._lib import HipError, HipLibraryMissing  # noqa: F401
 from .auxiva_pca import auxiva_pca  # noqa: F401
 from .ive import ogive  # noqa: F401
-from .overiva import get_device, get_precision, overiva, set_device, set_precision  # noqa: F401
+from .overiva import get_device, get_precision, last_solver_info, overiva, set_device, set_precision  # noqa: F401
 from .plan import DeviceX, Plan  # noqa: F401
 from .sharded import BinShardedSolver, disable_bin_sharding, enable_bin_sharding, shard_bounds  # noqa: F401
 
 __all__ = ["overiva", "auxiva_pca", "ogive", "Plan", "DeviceX", "BinShardedSolver", "enable_bin_sharding", "disable_bin_sharding",
-           "shard_bounds", "set_device", "get_device", "set_precision", "get_precision", "HipError", "HipLibraryMissing"]
+           "shard_bounds", "set_device", "get_device", "set_precision", "get_precision", "last_solver_info", "HipError", "HipLibraryMissing"]

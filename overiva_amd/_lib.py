@@ -7,6 +7,11 @@ product path fails with an explicit error.  ``python -m overiva_amd.build`` (or
 import ctypes as C
 import os
 
+# The host driver of this platform supports dmabuf IPC only: without this setting hipIpcGetMemHandle (the push exchange,
+# RCCL, sharing device tensors across processes) fails with "invalid argument".  It must be in the environment before
+# the HIP runtime initialises, i.e. before the first GPU call of the process.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -62,6 +67,7 @@ SIGNATURES = {
     "oiva_xchg_wait": [_vp, _vp, _i],
     "oiva_xchg_gathered": [_vp, _i, _vp],
     "oiva_xchg_poll": [_vp, _i, _i, _vp],
+    "oiva_xchg_force": [_vp, _i],
     "oiva_xchg_destroy": [_vp],
     "oiva_plan_get_w": [_vp, _vp, _i],
     "oiva_plan_sync": [_vp],

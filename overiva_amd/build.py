@@ -33,8 +33,12 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-# per-file flags (measured choices)
-EXTRA_FLAGS = {}
+# per-file flags (measured choices).  The X-resident kernels keep 128 accumulators in the architectural
+# registers and 128 floats of X in the accumulator file: with the scheduler's default register-pressure model they end
+# in scratch memory (40-450 bytes per lane), with the more exact trackers they do not.  The resource remarks of these
+# files are kept next to the objects (tests/test_host.py checks that no resident kernel uses scratch).
+_RESIDENT = ("-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-Rpass-analysis=kernel-resource-usage")
+EXTRA_FLAGS = {"kernels_resident_m8.hip": _RESIDENT, "kernels_resident_m4.hip": _RESIDENT}
 
 
 def _compile(src, extra=()):
@@ -46,9 +50,35 @@ def _compile(src, extra=()):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-        if r.stderr.strip():
+        if "-Rpass-analysis=kernel-resource-usage" in extra:
+            with open(os.path.splitext(obj)[0] + ".usage.txt", "w") as f:
+                f.write(r.stderr)
+        elif r.stderr.strip():
             sys.stderr.write(r.stderr)
     return obj
+
+
+def resident_kernel_usage():
+    """{kernel name: {"vgprs", "agprs", "scratch"}} of the X-resident kernels, from the remarks of the last build"""
+    import re
+
+    out = {}
+    for src in ("kernels_resident_m4", "kernels_resident_m8"):
+        path = os.path.join(OBJ, src + ".usage.txt")
+        if not os.path.exists(path):
+            continue
+        name = None
+        for line in open(path):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                out[name] = {}
+                continue
+            for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)")):
+                m = re.search(pat, line)
+                if m and name:
+                    out[name][key] = int(m.group(1))
+    return out
 
 
 def build_library(force=False, verbose=False):

@@ -113,21 +113,57 @@ struct PkAcc2 {
             diag[0][c] = fmaf(w.x, p, diag[0][c]);
             diag[1][c] = fmaf(w.y, p, diag[1][c]);
         }
-        // the compiler keeps inline asm in source order and knows no latencies: the products of a whole row are
-        // formed first (independent instructions back to back), then accumulated
-        int i0 = 0;
+        // The compiler keeps inline asm in source order and knows no latencies, so the order written here is the issue order:
+        // independent instructions back to back, a dependent one as far behind its producer as the registers allow.  Rows c
+        // and M-2-c of the upper triangle together hold M pairs (M-1-c and c+1), so taking the rows in such couples gives
+        // groups of M independent instructions (the middle row, M/2, stands alone) where row by row the groups shrink to 1 --
+        // a wave that is alone on its SIMD (the X-resident kernel) stalls on every short group, and hipcc pads each
+        // back-to-back dependent pair of asm statements with an s_nop.  Per accumulator the arithmetic is unchanged.
+        constexpr int NG = (M - 1 + 1) / 2;                      // couples of rows (+ the middle row when M - 1 is odd)
 #pragma unroll
-        for (int c = 0; c < M; ++c) {
+        for (int g = 0; g < NG; ++g) {
+            const int c1 = M - 2 - g;                            // partner row; == g for the middle row
+            const int n0 = M - 1 - g;                            // pairs of row g
+            const int n = c1 > g ? n0 + (g + 1) : n0;            // members of the group
             v2f p[M];
+            // member e of the group -> (row c, column d, index of the pair)
+#define OIVA_MEMBER(e)                                                                     \
+            const int c = (e) < n0 ? g : c1;                                               \
+            const int d = (e) < n0 ? g + 1 + (e) : c1 + 1 + ((e) - n0);                    \
+            const int ip = c * (M - 1) - (c * (c - 1)) / 2 + (d - c - 1);
 #pragma unroll
-            for (int d = c + 1; d < M; ++d) p[d] = pk_mul_lo_negim(x[c], x[d]);
+            for (int e = 0; e < M; ++e) {
+                if (e < n) {
+                    OIVA_MEMBER(e)
+                    (void)ip;
+                    p[e] = pk_mul_lo_negim(x[c], x[d]);
+                }
+            }
 #pragma unroll
-            for (int d = c + 1; d < M; ++d) p[d] = pk_fma_hi_swap(x[c], x[d], p[d]);
+            for (int e = 0; e < M; ++e) {
+                if (e < n) {
+                    OIVA_MEMBER(e)
+                    (void)ip;
+                    p[e] = pk_fma_hi_swap(x[c], x[d], p[e]);
+                }
+            }
 #pragma unroll
-            for (int d = c + 1; d < M; ++d) pair[0][i0 + d - c - 1] = pk_fma_w0(w, p[d], pair[0][i0 + d - c - 1]);
+            for (int e = 0; e < M; ++e) {
+                if (e < n) {
+                    OIVA_MEMBER(e)
+                    (void)d;
+                    pair[0][ip] = pk_fma_w0(w, p[e], pair[0][ip]);
+                }
+            }
 #pragma unroll
-            for (int d = c + 1; d < M; ++d) pair[1][i0 + d - c - 1] = pk_fma_w1(w, p[d], pair[1][i0 + d - c - 1]);
-            i0 += M - c - 1;
+            for (int e = 0; e < M; ++e) {
+                if (e < n) {
+                    OIVA_MEMBER(e)
+                    (void)d;
+                    pair[1][ip] = pk_fma_w1(w, p[e], pair[1][ip]);
+                }
+            }
+#undef OIVA_MEMBER
         }
     }
     // packed Hermitian layout (herm_pair_index): accumulator e = k * M*M + a

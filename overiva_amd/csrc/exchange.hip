@@ -195,6 +195,22 @@ int oiva_xchg_poll(oiva_xchg* x, int epoch, int timeout_ms, int* arrived) {
     }
 }
 
+int oiva_xchg_force(oiva_xchg* x, int epoch) {
+    XNEED(x && epoch >= 1, OIVA_ERR_ARG, "bad arguments");
+    XHIP(hipSetDevice(x->device));
+    // a host store of the value the stream waits for, through a stream of its own (the waiting stream is blocked, and
+    // nothing here may synchronise with it)
+    unsigned* counter = reinterpret_cast<unsigned*>(x->block + buffers_bytes(x->world, x->slot_bytes) + (epoch & 1) * kCounterStride);
+    const unsigned v = expected_count(x, epoch);
+    hipStream_t s = nullptr;
+    XHIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipError_t e = hipMemcpyAsync(counter, &v, sizeof(v), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
+    XHIP(e);
+    return OIVA_OK;
+}
+
 int oiva_xchg_destroy(oiva_xchg* x) {
     if (!x) return OIVA_OK;
     (void)hipSetDevice(x->device);

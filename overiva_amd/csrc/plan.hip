@@ -108,9 +108,9 @@ struct oiva_plan {
     double* res_vpart = nullptr;
     double* res_rsum = nullptr;
     float2* res_wpub = nullptr;
-    unsigned* res_flags = nullptr; // flag_p | flag_v | flag_w | ctrl
+    unsigned* res_flags = nullptr; // ctrl words ([0] give-up code)
     unsigned long long* res_stamps = nullptr;
-    size_t res_sync_bytes = 0;     // flags + ctrl
+    size_t res_block_bytes = 0;
     unsigned res_epoch = 0;
     int res_last_code = 0, res_launches = 0, res_fallbacks = 0, res_stamped = 0;
     int res_timeout_ms = 0, res_stall = -1;
@@ -297,7 +297,7 @@ int resident_alloc(oiva_plan* p) {
     const size_t b_vpart = up(((size_t)g.NS * Fp * K * NA + 2) * sizeof(double));
     const size_t b_rsum = up((size_t)g.NB * g.NS * K * sizeof(double));
     const size_t b_wpub = up(Fp * K * p->M * sizeof(float2));
-    const size_t b_flags = up(((size_t)3 * g.NB * g.NS + 16) * sizeof(unsigned));
+    const size_t b_flags = up(16 * sizeof(unsigned));
     const size_t b_stamps = up((size_t)kResidentStampIters * kResidentStamps * sizeof(unsigned long long));
     const size_t total = b_parts + b_vpart + b_rsum + b_wpub + b_flags + b_stamps;
     HIP_TRY(hipMalloc(&p->res_block, total));
@@ -314,7 +314,7 @@ int resident_alloc(oiva_plan* p) {
     p->res_flags = reinterpret_cast<unsigned*>(c);
     c += b_flags;
     p->res_stamps = reinterpret_cast<unsigned long long*>(c);
-    p->res_sync_bytes = b_flags;
+    p->res_block_bytes = total;
     p->res_epoch = 0;
     return OIVA_OK;
 }
@@ -326,7 +326,6 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     int rc = resident_alloc(p);
     if (rc) return rc;
     const ResidentGeom& g = p->rg;
-    const size_t nwg = (size_t)g.NB * g.NS;
     ResidentArgs a{};
     a.X = p->X;
     a.What = p->What;
@@ -337,10 +336,7 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     a.vpart = p->res_vpart;
     a.rsum = p->res_rsum;
     a.wpub = p->res_wpub;
-    a.flag_p = p->res_flags;
-    a.flag_v = p->res_flags + nwg;
-    a.flag_w = p->res_flags + 2 * nwg;
-    a.ctrl = p->res_flags + 3 * nwg;
+    a.ctrl = p->res_flags;
     a.stamps = n <= kResidentStampIters ? p->res_stamps : nullptr;
     a.T = p->T;
     a.F = p->F;
@@ -359,7 +355,7 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     if (code != 0) {
         // some wait ran into its time-out (workgroups not co-resident, or the test hook): W_hat was not written back.
         // Clear the flags, start the epochs over and stay on the four-launch path from here on.
-        HIP_TRY(hipMemset(p->res_flags, 0, p->res_sync_bytes));
+        HIP_TRY(hipMemset(p->res_block, 0, p->res_block_bytes));
         p->res_epoch = 0;
         p->res_last_code = (int)code;
         p->res_fallbacks++;
@@ -1036,7 +1032,7 @@ int oiva_plan_resident_phases(oiva_plan* p, double* phase_us, int* n_iter) {
     std::vector<unsigned long long> st((size_t)n * kResidentStamps);
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemcpy(st.data(), p->res_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    static_assert(OIVA_RESIDENT_PHASES == kResidentStamps - 1, "one phase between consecutive stamps");
+    static_assert(OIVA_RESIDENT_PHASES <= kResidentStamps - 1, "one phase between consecutive stamps");
     for (int it = 0; it < n; ++it)
         for (int i = 0; i < OIVA_RESIDENT_PHASES; ++i)
             phase_us[i] += (double)(st[(size_t)it * kResidentStamps + i + 1] - st[(size_t)it * kResidentStamps + i]) * 0.01 / n;   // 100 MHz ticks

@@ -27,14 +27,12 @@ struct ResidentArgs {
     double2* What64;        // complex128 copy kept by the float64 update (in/out) or nullptr
     int what64_valid;       // the complex128 copy holds the current state
     const double* Cx;       // [F][M*M] packed Hermitian, / T
-    // exchange buffers in this GPU's memory; every word of them is accessed with agent-scope atomics only
+    // exchange buffers in this GPU's memory; every word of them is one agent-scope atomic access that carries its
+    // epoch in spare mantissa bits (resident_kernel.inc)
     float* parts;           // [2 (epoch parity)][NB][NS * TW][K] partial source powers
     double* vpart;          // [NS][NB * 16][K][M*M] packed partial covariances
     double* rsum;           // [NB][NS][K] sum of the activations r over the split's frames
     float2* wpub;           // [NB * 16][K][M] conj of the demixing vectors, for the power phase
-    unsigned* flag_p;       // [NS][NB]  epoch of the last published parts
-    unsigned* flag_v;       // [NB][NS]  epoch of the last published covariance partials
-    unsigned* flag_w;       // [NB][NS]  epoch of the last published demixing vectors
     unsigned* ctrl;         // [0] give-up code (0 = fine)
     unsigned long long* stamps;   // [n_iter][kResidentStamps] 100 MHz timestamps of workgroup 0, or nullptr
     int T, F, F_total, model;
@@ -44,7 +42,7 @@ struct ResidentArgs {
     long long timeout_ticks;   // 100 MHz ticks a wait may take before the launch gives up
     int stall_block;        // test hook: this workgroup never publishes (-1: none)
 };
-constexpr int kResidentStamps = 8;
+constexpr int kResidentStamps = 10;
 
 // true when the shape can run resident on a chip of n_cu compute units (fills g)
 bool resident_geometry(int T, int F, int M, int K, int n_cu, ResidentGeom* g);

@@ -7,12 +7,18 @@ Two interchangeable transports with the same result layout (rank-major concatena
   every rank's buffer and signals a counter; no collective launch, no protocol -- built for the 100 KB payload of this
   path, where a collective is pure latency.
 
-``make_exchange`` validates the push transport against the collective before it is used (three epochs of a known
-pattern, host-side waits with a time-out, agreement of all ranks) and falls back to the collective if anything is off,
-so a platform on which peer mappings do not work costs a warning, not a wrong result or a hang.
+``make_exchange`` validates the push transport against the collective before it is used -- three epochs of a known
+pattern with host-side waits and a time-out, then one epoch in which the stream-side wait (``hipStreamWaitValue32``, the
+primitive the iterations block on) is enqueued 50 ms BEFORE the parts are pushed: it has to hold the stream that long and
+release it once every rank has pushed; a wait that does not return within 5 s is released by a host store -- and falls
+back to the collective, on every rank alike (rank 0's choice of transport is broadcast, the verdicts are gathered), if
+anything is off.  A platform on which peer mappings or peer atomics do not work thus costs a warning, not a wrong result
+or a hang.  ``HSA_ENABLE_IPC_MODE_LEGACY=0`` must be in the environment before the process's first GPU call (this
+platform's driver exports device memory through dmabuf only); ``overiva_amd._lib`` sets it at import unless it is set.
 """
 import ctypes as C
 import os
+import time
 import warnings
 
 import numpy as np
@@ -22,6 +28,7 @@ from . import _lib
 
 class CollectiveExchange:
     name = "collective"
+    fallback_reason = None      # why the push exchange was not used although it was asked for
 
     def __init__(self, engine, dist, group, world, p_local, p_all):
         self.dist, self.group, self.p_local, self.p_all = dist, group, p_local, p_all
@@ -57,10 +64,15 @@ class PushExchange:
         assert len(blob) == 64 * self.world
         _lib.check(self.lib.oiva_xchg_connect(self.h, blob))
 
-    def push(self, part_ptr=None):
-        self.epoch += 1
-        _lib.check(self.lib.oiva_xchg_push(self.h, C.c_void_p(self.stream), C.c_void_p(int(part_ptr or self.part_ptr)),
-                                           self.part_bytes, self.epoch))
+    def push(self, part_ptr=None, stream=None, advance=True):
+        if advance:
+            self.epoch += 1
+        _lib.check(self.lib.oiva_xchg_push(self.h, C.c_void_p(int(stream) if stream is not None else self.stream),
+                                           C.c_void_p(int(part_ptr or self.part_ptr)), self.part_bytes, self.epoch))
+
+    def force(self):
+        """release a stream wait of the current epoch that would never be satisfied (failed validation)"""
+        _lib.check(self.lib.oiva_xchg_force(self.h, self.epoch))
 
     def wait(self):
         _lib.check(self.lib.oiva_xchg_wait(self.h, C.c_void_p(self.stream), self.epoch))
@@ -105,6 +117,10 @@ def make_exchange(engine, dist, group, rank, world, p_local, p_all, prefer=None)
     """the transport for this run: the push exchange when it is asked for (``prefer="push"`` or ``OIVA_EXCHANGE=push``),
     available and validated on every rank, else the collective"""
     prefer = prefer or os.environ.get("OIVA_EXCHANGE", "collective")
+    # every rank must take the same branch below (the branches hold collectives): rank 0's choice counts
+    choice = [prefer]
+    dist.broadcast_object_list(choice, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    prefer = choice[0]
     fallback = CollectiveExchange(engine, dist, group, world, p_local, p_all)
     if prefer != "push" or world > 16 or not hasattr(engine, "plan"):
         return fallback
@@ -138,6 +154,34 @@ def make_exchange(engine, dist, group, rank, world, p_local, p_all, prefer=None)
                         raise RuntimeError(f"epoch {x.epoch}: gathered parts differ from what the ranks sent")
                     x.wait()                    # the stream-side wait the iterations use (already satisfied here)
                     engine.stream.synchronize()
+                # ... and once while it really BLOCKS: the wait is enqueued first, the push comes 50 ms later from a side
+                # stream.  The wait must hold the stream for those 50 ms and let it go within 5 s after every rank has
+                # pushed; a wait that never returns is released by a host store of the awaited value (force) -- the
+                # iterations would have hung exactly there.
+                flat.copy_((torch.arange(n, device=p_local.device, dtype=torch.float32) % 251) + 1000.0 * rank + 7)
+                engine.stream.synchronize()
+                side = torch.cuda.Stream(device=p_local.device)
+                x.epoch += 1
+                x.wait()
+                done = torch.cuda.Event()
+                done.record(engine.stream)
+                time.sleep(0.05)
+                held = not done.query()
+                x.push(stream=side.cuda_stream, advance=False)
+                t_end = time.monotonic() + 5.0
+                while not done.query() and time.monotonic() < t_end:
+                    time.sleep(0.001)
+                if not done.query():
+                    x.force()
+                    engine.stream.synchronize()
+                    raise RuntimeError("the stream-side wait did not return within 5 s of the pushes")
+                if not held:
+                    raise RuntimeError("the stream-side wait did not block while the parts were missing")
+                got = _device_view(torch, x.gathered_ptr(), n * world, p_local.device).clone().reshape(world, n)
+                want = torch.stack([(torch.arange(n, device=p_local.device, dtype=torch.float32) % 251) + 1000.0 * r + 7 for r in range(world)])
+                if not torch.equal(got, want):
+                    raise RuntimeError("blocking epoch: gathered parts differ from what the ranks sent")
+                side.synchronize()
                 flat.copy_(saved)
                 engine.stream.synchronize()
         except Exception as e:
@@ -154,4 +198,5 @@ def make_exchange(engine, dist, group, rank, world, p_local, p_all, prefer=None)
                       "); using the torch.distributed all-gather")
     if x is not None:
         x.close()
+    fallback.fallback_reason = "; ".join(f"rank {r}: {v[1]}" for r, v in enumerate(verdicts) if not v[0])
     return fallback

@@ -52,6 +52,15 @@ def get_precision():
     return _precision
 
 
+_last_info = {}
+
+
+def last_solver_info():
+    """what the last ``overiva()`` call of this process ran on: arithmetic mode, whether the X-resident kernel was used
+    (launches) and whether it had to fall back to the four-launch path"""
+    return dict(_last_info)
+
+
 def set_device(index):
     """GPU used by subsequent calls in this process (default: $LOCAL_RANK, else 0)."""
     global _device
@@ -74,8 +83,9 @@ def _complex_dtype(X):
 
 def eig_init(Cx, n_src):
     """W0 from the principal eigenvectors of the input covariance (reference overiva.py:106-109), with host LAPACK as
-    in the reference.  The single-GPU path uses the device eigensolver instead (``Plan.set_w_eig``: same vectors, same
-    phase convention -- largest component real); this host form serves the bin-sharded solver."""
+    in the reference.  The product paths (single GPU and bin-sharded) use the device eigensolver instead
+    (``Plan.set_w_eig``: same vectors, same phase convention -- largest component real); this host form serves engines
+    without one (the CPU test engine of tests/gloo_worker.py)."""
     vals, vecs = np.linalg.eig(np.asarray(Cx, dtype=np.complex128))
     F, M, _ = Cx.shape
     W0 = np.empty((F, M, n_src), dtype=np.complex128)
@@ -151,11 +161,9 @@ def overiva(
     try:
         solver.set_x(X)
         solver.covariance()
-        if W0 is None and init_eig and hasattr(solver, "set_w_eig"):
-            solver.set_w_eig()                      # overiva.py:106-109 on the device
+        if W0 is None and init_eig:
+            solver.set_w_eig()                      # overiva.py:106-109 on the device (per shard when the bins are sharded)
         else:
-            if W0 is None and init_eig:
-                W0 = eig_init(solver.get_cx(), n_src)
             solver.set_w(W0)
 
         epoch = 0
@@ -191,8 +199,13 @@ class _SingleDevice:
         self.plan = Plan(T, F, M, K, model, device=get_device())
         self.plan.set_precision(precision)
         self.wdtype = np.complex64 if precision == "fast" else np.complex128
+        self.precision = precision
         if T * F * M >= self.GRAPH_MIN_ELEMENTS:
             self.plan.use_graph(True)
+        # the loop body as one persistent launch with X on chip wherever the shape qualifies (csrc/resident_kernel.inc);
+        # $OIVA_RESIDENT=0 keeps the four-launch path
+        if precision != "precise" and os.environ.get("OIVA_RESIDENT", "1") != "0" and self.plan.resident_info()["qualifies"]:
+            self.plan.set_resident(True)
 
     def set_x(self, X):
         self.plan.set_x(X)
@@ -219,4 +232,9 @@ class _SingleDevice:
         return self.plan.get_w(self.wdtype)
 
     def close(self):
+        global _last_info
+        if getattr(self.plan, "h", None):
+            info = self.plan.resident_info()
+            _last_info = {"precision": self.precision, "sharded": False, "resident_launches": info["launches"],
+                          "resident_fallbacks": info["fallbacks"], "resident_give_up_code": info["last_give_up_code"]}
         self.plan.close()

@@ -227,7 +227,7 @@ class Plan:
     # -- X-resident iteration (include/overiva_hip.h, csrc/resident_kernel.inc) -------------------
     RESIDENT_INFO = ("qualifies", "enabled", "bin_groups", "frame_splits", "frames_per_split", "frames_per_lane",
                      "frames_in_registers", "lds_bytes", "last_give_up_code", "launches", "fallbacks", "x_bytes_per_cu")
-    RESIDENT_PHASES = ("demix_power", "wait_parts", "activation", "weighted_cov", "wait_partials", "ip_update", "wait_w")
+    RESIDENT_PHASES = ("demix_power", "parts", "activation", "cov_accumulate", "cov_reduce", "wait_partials", "ip_update", "wait_w")
 
     def set_resident(self, enable=True):
         """the loop body as ONE persistent launch per ``iterate`` call with X held on chip; ValueError when the shape

@@ -109,6 +109,9 @@ class HipEngine:
     def set_w(self, W0):
         self.plan.set_w(W0)
 
+    def set_w_eig(self):
+        self.plan.set_w_eig()
+
     def power(self):
         self.plan.power()
 
@@ -184,6 +187,17 @@ class BinShardedSolver:
         if W0 is not None:
             W0 = np.broadcast_to(np.asarray(W0), (self.F, self.M, self.K))[self.f0:self.f1]
         self.engine.set_w(W0)
+
+    def set_w_eig(self):
+        """``init_eig`` (overiva.py:106-109): the eigenvectors are per bin, so every rank runs the device eigensolver on its
+        own shard and nothing is exchanged; an engine without one (the CPU test engine) gets LAPACK's on the gathered Cx"""
+        if hasattr(self.engine, "set_w_eig"):
+            with self.engine.stream_ctx():
+                self.engine.set_w_eig()
+        else:
+            from .overiva import eig_init
+
+            self.set_w(eig_init(self.get_cx(), self.K))
 
     def iterate(self, n):
         with self.engine.stream_ctx():

@@ -79,8 +79,15 @@ class OracleEngine:
             Y = Y * np.conj(orc.projection_back(Y, self.X[:, :, 0])[None])
         return Y.astype(np.complex64)
 
+    # like HipEngine in the 'mixed' / 'precise' modes when $OIVA_TEST_WDTYPE=c128: W travels as complex128
+    wdtype = np.complex128 if os.environ.get("OIVA_TEST_WDTYPE") == "c128" else np.complex64
+
     def get_w(self):
-        return np.ascontiguousarray(self.What[:, :, :self.K]).astype(np.complex64)
+        import torch.distributed as dist
+
+        if os.environ.get("OIVA_TEST_SINGULAR_RANK") == str(dist.get_rank()):
+            raise np.linalg.LinAlgError("demixing matrix holds non-finite values (test)")
+        return np.ascontiguousarray(self.What[:, :, :self.K]).astype(self.wdtype)
 
     def to_comm(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a))
@@ -110,6 +117,19 @@ def main():
     s.set_w(W0)
     s.iterate(n_iter)
     Y = s.demix(True)
+    if os.environ.get("OIVA_TEST_SINGULAR_RANK") is not None:
+        # one rank's bins are singular: EVERY rank must get the error (nobody may be left waiting in the gather)
+        try:
+            s.get_w()
+            outcome = "no error"
+        except np.linalg.LinAlgError as e:
+            outcome = "LinAlgError: " + str(e)
+        s.close()
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write(outcome)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     W = s.get_w()
     s.close()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), Y=Y, W=W, Cx=Cx, f0=s.f0, f1=s.f1)

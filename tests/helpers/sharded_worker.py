@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 def main():
     out, T, F, M, K, model, precision, n_iter = sys.argv[1], *[int(a) for a in sys.argv[2:6]], sys.argv[6], sys.argv[7], int(sys.argv[8])
     exchange = sys.argv[9] if len(sys.argv) > 9 else "collective"
+    init_eig = len(sys.argv) > 10 and sys.argv[10] == "eig"
     import torch
     import torch.distributed as dist
 
@@ -27,7 +28,7 @@ def main():
 
     warnings.simplefilter("error")                    # a fall-back to the collective must fail the test, not pass silently
     seen = []
-    Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, model=model, return_filters=True,
+    Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, model=model, return_filters=True, init_eig=init_eig,
                       callback=lambda y: seen.append(y.copy()))
     oa.disable_bin_sharding()
     if dist.get_rank() == 0:

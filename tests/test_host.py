@@ -136,3 +136,22 @@ def test_plain_c_program_links_against_the_abi(lib, tmp_path):
     if not has_gpu():
         run = subprocess.run([str(exe)], capture_output=True, text=True)
         assert run.returncode == 2 and "no GPU" in run.stderr      # loud failure, no CPU path
+
+
+def test_resident_kernels_use_no_scratch_memory(lib):
+    """the X-resident kernels hold 128 covariance accumulators in the architectural registers and up to 128 floats of X in
+    the accumulator file; a build whose register allocation falls over into scratch memory (per-lane stack in HBM) would
+    still be correct and quietly several times slower, so the build keeps hipcc's resource remarks and this checks them"""
+    import os
+
+    from overiva_amd import build
+
+    if not any(os.path.exists(os.path.join(build.OBJ, s + ".usage.txt")) for s in ("kernels_resident_m4", "kernels_resident_m8")):
+        build.build_library(force=True)          # objects came from a build without remarks
+    usage = build.resident_kernel_usage()
+    assert len(usage) >= 12, usage.keys()
+    for name, u in usage.items():
+        assert u["scratch"] == 0, (name, u)
+        assert u["vgprs"] + u["agprs"] <= 512
+    # the variants that keep 8 frames per lane in registers need the accumulator file for them
+    assert any(u["agprs"] >= 128 for name, u in usage.items() if "ILi8ELi2ELi8E" in name)

@@ -83,7 +83,7 @@ def test_reference_sized_problem(M, n_iter):
         try:
             Y, w = oa.ogive(X, n_iter=n_iter, tol=0.0, proj_back=True, return_filters=True)
         finally:
-            oa.set_precision("precise")
+            oa.set_precision("auto")
         e_w, e_y = rel_err(w, wr), rel_err(Y, Yr)
         print(f"\n[ogive] 2049 x 160 x {M}, {n_iter} epochs, {mode}: w err {e_w:.2e}, Y err {e_y:.2e} (reference c64 floor {floor:.1e})")
         assert e_w < max(TOL, floors * floor) and e_y < max(TOL, 3 * floors * floor)

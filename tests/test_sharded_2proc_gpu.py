@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, world, T, F, M, K, model, precision, n_iter, port, exchange="collective"):
+def _run(tmp_path, world, T, F, M, K, model, precision, n_iter, port, exchange="collective", init="eye"):
     out = str(tmp_path / f"sharded_{world}.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "tests", "helpers", "sharded_worker.py"), out, str(T), str(F), str(M),
-           str(K), model, precision, str(n_iter), exchange]
+           str(K), model, precision, str(n_iter), exchange, init]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -37,18 +37,39 @@ def test_processes_sharing_one_gpu(tmp_path, world, F, model, precision, exchang
     got = _run(tmp_path, world, T, F, M, K, model, precision, n_iter, 29600 + world + (10 if exchange == "push" else 0), exchange)
     assert int(got["world"]) == world
     oa.set_precision(precision)
+    os.environ["OIVA_RESIDENT"] = "0"        # the ranks run the four-launch path: compare with the same path in one process
     try:
         X = orc.synth_mixture(T, F, M, K, seed=11)
         seen = []
         Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, model=model, return_filters=True,
                           callback=lambda y: seen.append(y.copy()))
     finally:
-        oa.set_precision("precise")
+        oa.set_precision("auto")
+        os.environ.pop("OIVA_RESIDENT", None)
     assert got["cb"].shape == np.stack(seen).shape
     if F % (64 * world) == 0:        # shard boundaries on 64-bin batches: the same bits as one process
         assert np.array_equal(got["W"], W) and np.array_equal(got["Y"], Y) and np.array_equal(got["cb"], np.stack(seen))
     else:                            # a batch straddles a boundary: the activation sums in another grouping
         assert orc.rel_err(got["W"], W) < 1e-5 and orc.rel_err(got["Y"], Y) < 1e-5
+
+
+def test_sharded_init_eig_runs_on_every_ranks_device(tmp_path):
+    """init_eig (overiva.py:106-109) with the bins sharded: every rank runs the device eigensolver on its own shard;
+    same bits as one process (the eigenvectors are per bin, nothing is exchanged for them)"""
+    import overiva_amd as oa
+    from oracle import overiva_oracle as orc
+
+    T, F, M, K, n_iter = 300, 128, 4, 2, 6
+    got = _run(tmp_path, 2, T, F, M, K, "laplace", "mixed", n_iter, 29631, "collective", "eig")
+    oa.set_precision("mixed")
+    os.environ["OIVA_RESIDENT"] = "0"
+    try:
+        X = orc.synth_mixture(T, F, M, K, seed=11)
+        Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, return_filters=True, init_eig=True)
+    finally:
+        oa.set_precision("auto")
+        os.environ.pop("OIVA_RESIDENT", None)
+    assert np.array_equal(got["W"], W) and np.array_equal(got["Y"], Y)
 
 
 @pytest.mark.parametrize("exchange", ["collective", "push"])

@@ -57,3 +57,22 @@ def test_sharded_equals_unsharded(tmp_path, world, model):
     assert orc.rel_err(outs[0]["W"], Wr) < 1e-5
     assert orc.rel_err(outs[0]["Y"], Yr) < 1e-5
     assert orc.rel_err(outs[0]["Cx"], orc.input_covariance(X.astype(np.complex128))) < 1e-6
+
+
+@pytest.mark.parametrize("wdtype", ["c64", "c128"])
+def test_singular_bin_on_one_rank_raises_on_every_rank(tmp_path, wdtype):
+    """BinShardedSolver.get_w gathers before it judges: when ONE rank's engine reports a singular solve, every rank raises
+    LinAlgError instead of waiting in the all-gather -- also when W travels as complex128 (the 'mixed' / 'precise' modes),
+    where the failing rank's NaN placeholder must have the same element size as what the healthy ranks send"""
+    world, port = 3, _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", OIVA_TEST_SINGULAR_RANK="1", OIVA_TEST_WDTYPE=wdtype)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "gloo_worker.py"), str(tmp_path), "laplace", "2"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()[-3000:]
+    for rank in range(world):
+        assert (tmp_path / f"rank{rank}.txt").read_text().startswith("LinAlgError"), rank
