@@ -167,6 +167,9 @@ def _time_plan(plan, args, repeats=0):
     bracketed by HIP events on the plan's stream"""
     import torch
 
+    # (an untimed pass of the same K steps first: the first replay of the captured graphs and the clock ramp of a GPU that
+    #  was idle cost 2-4 % of a 4-10 ms measurement; the W warm-up steps of the contract follow)
+    plan.iterate(args.steps)
     plan.iterate(args.warmup)
     plan.sync()
     torch.cuda.synchronize()

@@ -234,12 +234,20 @@ int oiva_plan_set_precision(oiva_plan *p, int flags);
  *   oiva_plan_resident_debug : test hooks -- time-out of a wait in milliseconds (0: default 2000), and the index of a
  *                              workgroup that never publishes (-1: none), which makes the launch give up
  */
+struct oiva_xchg;
 #define OIVA_RESIDENT_INFO 12
 #define OIVA_RESIDENT_PHASES 8
 int oiva_plan_set_resident(oiva_plan *p, int enable);
 int oiva_plan_resident_info(oiva_plan *p, int *info /* OIVA_RESIDENT_INFO ints */);
 int oiva_plan_resident_phases(oiva_plan *p, double *phase_us /* OIVA_RESIDENT_PHASES */, int *n_iter);
 int oiva_plan_resident_debug(oiva_plan *p, int timeout_ms, int stall_block);
+/* Bins sharded over the GPUs of a node: give the plan of a shard a connected oiva_xchg (below) whose slot is
+ * frame_splits * frames_per_split * K * 4 bytes; the resident kernel then exchanges the ranks' partial source powers
+ * (overiva.py:152-155) itself -- one workgroup per frame split stores the rank's sums into every rank's buffer (peer
+ * stores over xGMI), every workgroup adds the ranks' sums in rank order -- and oiva_plan_iterate works on a shard
+ * (F < F_total).  Every rank must call oiva_plan_iterate with the same counts.  A launch that gives up returns
+ * OIVA_ERR_STATE (nothing written).  x = NULL disconnects. */
+int oiva_plan_resident_connect(oiva_plan *p, struct oiva_xchg *x);
 
 /*
  * Test-only stage access (per-kernel parity tests call these through the same ABI).

@@ -70,6 +70,16 @@ __global__ __launch_bounds__(kBlock) void push_kernel(PushArgs a, const V* __res
 
 using namespace oiva;
 
+// the mapped gather buffers of a connected exchange, for the X-resident kernel's in-kernel exchange (plan.hip)
+int oiva::xchg_peers(oiva_xchg* x, char** peers, int* rank, int* world, size_t* slot_bytes) {
+    if (!x || !(x->connected || x->world == 1)) return -1;
+    for (int r = 0; r < OIVA_XCHG_MAX_RANKS; ++r) peers[r] = r < x->world ? x->peer[r] : nullptr;
+    *rank = x->rank;
+    *world = x->world;
+    *slot_bytes = x->slot_bytes;
+    return 0;
+}
+
 #define XNEED(cond, code, msg) \
     do {                       \
         if (!(cond)) return fail_with(code, msg); \

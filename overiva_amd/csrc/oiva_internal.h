@@ -11,6 +11,8 @@ namespace oiva {
 
 // records the thread-local message oiva_last_error() returns and hands back `code` (defined in plan.hip)
 int fail_with(int code, const std::string& msg);
+// exchange.hip: rank / world / slot size and every rank's gather buffer as mapped in this process; -1 unless connected
+int xchg_peers(oiva_xchg* x, char** peers, int* rank, int* world, size_t* slot_bytes);
 
 // ---- lane geometry shared by the streaming kernels -------------------------------------------
 // A wave is 16 bins x 4 frame phases: lane l -> bin (l & 15), phase (l >> 4).  The 16 bins of one

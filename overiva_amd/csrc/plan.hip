@@ -114,6 +114,8 @@ struct oiva_plan {
     unsigned res_epoch = 0;
     int res_last_code = 0, res_launches = 0, res_fallbacks = 0, res_stamped = 0;
     int res_timeout_ms = 0, res_stall = -1;
+    char* res_gath[OIVA_XCHG_MAX_RANKS] = {};   // every rank's gather buffer (bins sharded over GPUs), else unused
+    int res_rank = 0, res_world = 1;
     hipGraphExec_t graph_exec = nullptr;        // one iteration
     hipGraphExec_t graph_batch_exec = nullptr;  // kGraphBatch iterations
     hipEvent_t ev[2] = {};
@@ -285,7 +287,7 @@ int one_iteration(oiva_plan* p) {
 constexpr int kResidentStampIters = 256;
 
 bool resident_applies(const oiva_plan* p) {
-    return p->res_on && p->res_ok && p->F == p->F_total && !p->cov_f64() && !p->raw_weights && !p->wscale_pending;
+    return p->res_on && p->res_ok && (p->F == p->F_total || p->res_world > 1) && !p->cov_f64() && !p->raw_weights && !p->wscale_pending;
 }
 
 int resident_alloc(oiva_plan* p) {
@@ -347,6 +349,9 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     a.epoch0 = p->res_epoch;
     a.timeout_ticks = (long long)(p->res_timeout_ms > 0 ? p->res_timeout_ms : 2000) * 100000;   // 100 MHz clock
     a.stall_block = p->res_stall;
+    a.rank = p->res_rank;
+    a.world = p->res_world;
+    for (int r = 0; r < OIVA_XCHG_MAX_RANKS; ++r) a.gath[r] = reinterpret_cast<float*>(p->res_gath[r]);
     HIP_TRY(launch_resident(p->stream, a, p->M, p->K, p->upd_f64()));
     p->res_launches++;
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -361,6 +366,9 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
         p->res_fallbacks++;
         p->res_on = false;
         p->res_stamped = 0;
+        if (p->res_world > 1)      // the other ranks' state is unknown: no silent fall-back, the caller has to decide for all of them
+            return fail(OIVA_ERR_STATE, "the X-resident launch gave up waiting (code " + std::to_string(code) +
+                                        "): a rank did not deliver its parts in time; W_hat of this rank is unchanged");
         return OIVA_OK;
     }
     p->res_epoch += (unsigned)n;
@@ -725,8 +733,8 @@ int oiva_plan_iterate(oiva_plan* p, int n) {
     int rc = check_ready(p);
     if (rc) return rc;
     NEED(n >= 0, OIVA_ERR_ARG, "negative iteration count");
-    NEED(p->F == p->F_total, OIVA_ERR_STATE,
-         "plan owns a bin shard: drive it with oiva_plan_power / all-gather / oiva_plan_update");
+    NEED(p->F == p->F_total || resident_applies(p), OIVA_ERR_STATE,
+         "plan owns a bin shard: drive it with oiva_plan_power / all-gather / oiva_plan_update (or connect the X-resident exchange)");
     DeviceGuard guard(p->device);
     if (n == 0) return OIVA_OK;
     if (resident_applies(p)) {
@@ -1010,6 +1018,28 @@ int oiva_plan_set_resident(oiva_plan* p, int enable) {
     int rc = resident_alloc(p);
     if (rc) return rc;
     p->res_on = true;
+    return OIVA_OK;
+}
+
+int oiva_plan_resident_connect(oiva_plan* p, oiva_xchg* x) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    if (!x) {                                  // back to a single rank
+        p->res_world = 1;
+        p->res_rank = 0;
+        for (auto& g : p->res_gath) g = nullptr;
+        return OIVA_OK;
+    }
+    NEED(p->res_ok, OIVA_ERR_ARG, "shape does not qualify for the X-resident iteration");
+    char* peers[OIVA_XCHG_MAX_RANKS];
+    int rank = 0, world = 1;
+    size_t slot = 0;
+    NEED(xchg_peers(x, peers, &rank, &world, &slot) == 0, OIVA_ERR_STATE, "exchange not connected");
+    const size_t want = (size_t)p->rg.NS * p->rg.TW * p->K * sizeof(float);
+    NEED(slot == want, OIVA_ERR_ARG, "exchange slot size must be frame_splits * frames_per_split * K * 4 bytes of THIS plan "
+                                     "(every rank must run the same split geometry)");
+    for (int r = 0; r < OIVA_XCHG_MAX_RANKS; ++r) p->res_gath[r] = peers[r];
+    p->res_rank = rank;
+    p->res_world = world;
     return OIVA_OK;
 }
 

@@ -34,6 +34,10 @@ struct ResidentArgs {
     double* rsum;           // [NB][NS][K] sum of the activations r over the split's frames
     float2* wpub;           // [NB * 16][K][M] conj of the demixing vectors, for the power phase
     unsigned* ctrl;         // [0] give-up code (0 = fine)
+    // bins sharded over `world` GPUs (world == 1: unused): gath[r] = rank r's gather buffer as mapped here, fine-grained
+    // memory, [2 (epoch parity)][world][NS * TW][K] sums of the ranks' parts; every rank must run the same NS x TW
+    float* gath[OIVA_XCHG_MAX_RANKS];
+    int rank, world;
     unsigned long long* stamps;   // [n_iter][kResidentStamps] 100 MHz timestamps of workgroup 0, or nullptr
     int T, F, F_total, model;
     ResidentGeom g;

@@ -246,6 +246,11 @@ class Plan:
         _lib.check(self.lib.oiva_plan_resident_phases(self.h, arr, C.byref(n)))
         return dict(zip(self.RESIDENT_PHASES, list(arr))), n.value
 
+    def resident_connect(self, xchg_handle):
+        """bins sharded over GPUs: the connected exchange (``exchange.PushExchange.h``) the resident kernel pushes its
+        rank's partial powers through; None disconnects"""
+        _lib.check(self.lib.oiva_plan_resident_connect(self.h, xchg_handle))
+
     def resident_debug(self, timeout_ms=0, stall_block=-1):
         _lib.check(self.lib.oiva_plan_resident_debug(self.h, int(timeout_ms), int(stall_block)))
 

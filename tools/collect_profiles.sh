@@ -7,16 +7,16 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py"
-HEAD="--steps 6 --warmup 2 --no-cpu --no-other-mode --graph 0"
+HEAD="--steps 6 --warmup 2 --no-cpu --no-other-mode --no-configs --graph 0"
 
 # bench lines (the default run carries the CPU baseline)
 $B > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
-$B --config cfg5 --no-cpu > "$OUT/bench_cfg5.json" 2> "$OUT/bench_cfg5.err"
+$B --config cfg5 --no-cpu --precision fast > "$OUT/bench_cfg5.json" 2> "$OUT/bench_cfg5.err"
 $B --force-sharded --no-cpu --no-other-mode > "$OUT/bench_sharded_1rank.json" 2> "$OUT/bench_sharded.err"
 
 # kernel-trace statistics of the bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_headline" -o s -- $B --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_cfg5" -o s -- $B --config cfg5 --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_cfg5" -o s -- $B --config cfg5 --precision fast --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
 
 # counters, headline shape, fast mode, eager launches
 i=0
@@ -39,8 +39,16 @@ i=0
 for c in "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
          "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i + 1))
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_cfg5/p$i" -o p -- $B --config cfg5 $HEAD > /dev/null 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_cfg5/p$i" -o p -- $B --config cfg5 --precision fast $HEAD > /dev/null 2>&1
 done
+# the X-resident kernel: HBM traffic per launch of 50 iterations (X once + the exchange words), shard of the headline shape and configs[1]
+i=0
+for c in "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_resident_shard8/p$i" -o p -- python3 $ROOT/tools/resident_case.py 4000 256 8 2 50 > /dev/null 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_resident_cfg2/p$i" -o p -- python3 $ROOT/tools/resident_case.py 1000 513 4 2 50 > /dev/null 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_resident" -o s -- python3 $ROOT/tools/resident_case.py 4000 256 8 2 50 > "$OUT/resident_shard8.log" 2>&1
 # keep what travels back small: drop the raw kernel traces of the --stats runs
 find "$OUT" -name "*_kernel_trace.csv" -path "*stats_*" -delete
 find "$OUT" -name "*_agent_info.csv" -delete

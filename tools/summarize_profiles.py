@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, re, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "gpurun_out", "prof")
 DST = os.path.join(REPO, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def short(name):
@@ -61,6 +61,19 @@ def main():
             json.dump(json.loads(line), open(os.path.join(DST, f"{TAG}_{out}"), "w"), indent=1)
     stats("stats_headline", f"{TAG}_kernel_stats.csv")
     stats("stats_cfg5", f"{TAG}_cfg5_kernel_stats.csv")
+    stats("stats_resident", f"{TAG}_resident_shard8_kernel_stats.csv")
+    res = {}
+    for sub, what in (("pmc_resident_shard8", "256 x 4000 x 8 / 2 (65.5 MB of X), 50 iterations per launch"),
+                      ("pmc_resident_cfg2", "513 x 1000 x 4 / 2 (16.4 MB of X), 50 iterations per launch")):
+        for k, cs in counters(sub).items():
+            if k.startswith("resident_kernel") and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                res[f"{k} on {what}"] = {"FETCH_SIZE_KiB_avg": cs["FETCH_SIZE"], "WRITE_SIZE_KiB_avg": cs["WRITE_SIZE"],
+                                         "fetch_bytes_corrected_x2": cs["FETCH_SIZE"] * 2048, "fetch_bytes_uncorrected": cs["FETCH_SIZE"] * 1024,
+                                         "write_bytes": cs["WRITE_SIZE"] * 1024, "iterations_per_launch": 50}
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around tools/resident_case.py: HBM-side bytes of ONE launch of the "
+                       "X-resident kernel = 50 iterations.  X is read once per launch; the rest is the exchange words (8-byte atomic loads "
+                       "and stores, for which the x2 FETCH correction of 16 B/lane streaming reads need not hold: both figures are given)",
+               "kernels": res}, open(os.path.join(DST, f"{TAG}_pmc_resident_traffic.json"), "w"), indent=1)
 
     head = counters("pmc_headline")
     traffic = {}
