@@ -48,6 +48,9 @@ CONFIGS = {
     "cfg5": dict(T=4000, F=2048, M=16, K=16, name="determined AuxIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[4])"),
     "cfg2": dict(T=1000, F=513, M=4, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[1])"),
     "shard8": dict(T=4000, F=256, M=8, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64: one rank's shard of the headline shape at 8 GPUs (BASELINE.json configs[3])"),
+    # test-only: small enough for the X-resident kernels of two ranks to be resident side by side on ONE GPU
+    # (tests/test_sharded_2proc_gpu.py); not a BASELINE config
+    "tiny": dict(T=600, F=128, M=4, K=2, name="test shape {F} bins x {T} frames x {M} mics / {K} src"),
 }
 T, F, M, K = 4000, 2048, 8, 2
 WORKLOAD = CONFIGS["headline"]["name"].format(T=T, F=F, M=M, K=K)
@@ -383,72 +386,95 @@ def run_sharded(args):
         p_local = eng.exchange_buffer(ppr)
         p_all = eng.new_gather_buffer(world)
 
-        # transport of the per-iteration all-gather: RCCL through torch.distributed (default), or the library's push
-        # exchange (opt-in; validated -- including a stream wait that really blocks -- before it is used, exchange.py)
+        # transport of the per-iteration all-gather: RCCL through torch.distributed (default), the library's push exchange
+        # (opt-in; validated -- including a stream wait that really blocks -- before it is used, exchange.py), or none at
+        # all: the X-resident kernel with the exchange inside it (opt-in; every rank's shard must fit on chip)
         from overiva_amd.exchange import make_exchange
 
-        xchg = make_exchange(eng, dist, None, rank, world, p_local, p_all, prefer=args.exchange)
+        resident_refused = None
+        if args.exchange == "resident":
+            resident_refused = eng.setup_resident(dist, None, rank, world) if args.precision != "precise" else "precise arithmetic"
+            if resident_refused is not None and rank == 0:
+                print(f"[bench] X-resident exchange not used: {resident_refused}; collective", file=sys.stderr)
+        resident = args.exchange == "resident" and resident_refused is None
+        xchg = make_exchange(eng, dist, None, rank, world, p_local, p_all, prefer="collective" if args.exchange == "resident" else args.exchange)
         nparts = world * ppr
 
         def step():
             eng.power()
             eng.update_ptr(xchg.gather(), nparts)
 
-        for _ in range(args.warmup):
-            step()
-        stream.synchronize()
-        # per-rank stage breakdown (eager, events on the shared stream): power pass | all-gather | activation +
-        # covariance + update
-        # roofline of the dominant kernel on this rank's shard: the covariance kernel alone, HIP events on the plan's
-        # stream (same definition as the single-GPU line, with this rank's number of bins).  Like the stage breakdown
-        # it runs before the wall-clock measurement, which then does not start on a cold GPU.
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        acc = [0.0, 0.0, 0.0]
-        nb = max(5, args.steps)
-        for _ in range(nb):
-            ev[0].record(stream)
-            eng.power()
-            ev[1].record(stream)
-            gathered = xchg.gather()
-            ev[2].record(stream)
-            eng.update_ptr(gathered, nparts)
-            ev[3].record(stream)
-            stream.synchronize()
-            for i in range(3):
-                acc[i] += ev[i].elapsed_time(ev[i + 1]) / nb
-        breakdown = {"power_ms": acc[0], "all_gather_ms": acc[1], "activation_cov_update_ms": acc[2]}
-        cov_ms = eng.plan.t_time_stage("weighted_cov", 20)
-        stream.synchronize()
         graph = None
-        spg = 8            # iterations per captured graph (kernels + the RCCL all-gather)
-        # Capturing RCCL collectives in a graph was verified with one rank only (this pool has 1-GPU boxes), so
-        # the multi-rank default is eager launches (host cost per step ~45 us < device time); --graph 2 opts in.
-        if args.graph >= 2 and args.steps >= spg and xchg.name == "collective":
-            try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=stream):
-                    for _ in range(spg):
-                        step()
-                graph.replay()
+        if resident:
+            # one persistent launch per call: W warm-up iterations, then exactly K timed ones
+            eng.plan.iterate(args.steps)
+            eng.plan.iterate(args.warmup)
+            stream.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.plan.iterate(args.steps)
+            stream.synchronize()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            phases, _ = eng.plan.resident_phases()
+            breakdown = {"resident_phase_us_workgroup0": phases}
+            cov_ms = None
+        else:
+            for _ in range(args.warmup):
+                step()
+            stream.synchronize()
+            # per-rank stage breakdown (eager, events on the shared stream): power pass | all-gather | activation +
+            # covariance + update
+            # roofline of the dominant kernel on this rank's shard: the covariance kernel alone, HIP events on the plan's
+            # stream (same definition as the single-GPU line, with this rank's number of bins).  Like the stage breakdown
+            # it runs before the wall-clock measurement, which then does not start on a cold GPU.
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            acc = [0.0, 0.0, 0.0]
+            nb = max(5, args.steps)
+            for _ in range(nb):
+                ev[0].record(stream)
+                eng.power()
+                ev[1].record(stream)
+                gathered = xchg.gather()
+                ev[2].record(stream)
+                eng.update_ptr(gathered, nparts)
+                ev[3].record(stream)
                 stream.synchronize()
-            except Exception as e:  # capture of the collective not supported: stay eager
-                if rank == 0:
-                    print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); eager", file=sys.stderr)
-                graph = None
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        done = 0
-        if graph is not None:
-            while done + spg <= args.steps:
-                graph.replay()
-                done += spg
-        while done < args.steps:       # remainder (or everything, when eager): exactly K steps in total
-            step()
-            done += 1
-        stream.synchronize()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+                for i in range(3):
+                    acc[i] += ev[i].elapsed_time(ev[i + 1]) / nb
+            breakdown = {"power_ms": acc[0], "all_gather_ms": acc[1], "activation_cov_update_ms": acc[2]}
+            cov_ms = eng.plan.t_time_stage("weighted_cov", 20)
+            stream.synchronize()
+            spg = 8            # iterations per captured graph (kernels + the RCCL all-gather)
+            # Capturing RCCL collectives in a graph was verified with one rank only (this pool has 1-GPU boxes), so
+            # the multi-rank default is eager launches (host cost per step ~45 us < device time); --graph 2 opts in.
+            if args.graph >= 2 and args.steps >= spg and xchg.name == "collective":
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=stream):
+                        for _ in range(spg):
+                            step()
+                    graph.replay()
+                    stream.synchronize()
+                except Exception as e:  # capture of the collective not supported: stay eager
+                    if rank == 0:
+                        print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); eager", file=sys.stderr)
+                    graph = None
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            done = 0
+            if graph is not None:
+                while done + spg <= args.steps:
+                    graph.replay()
+                    done += spg
+            while done < args.steps:       # remainder (or everything, when eager): exactly K steps in total
+                step()
+                done += 1
+            stream.synchronize()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
     dist.barrier()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -462,14 +488,22 @@ def run_sharded(args):
     out = result_line(args, world, float(tmax.item()))
     out["config"]["graph"] = graph is not None
     fl = f1 - f0
-    _, roof = _cov_roofline((T, fl, M, K), args.precision, cov_ms)
-    roof["kernel"] += f" on rank 0's {fl} bins"
-    roof["per"] = "GPU"
-    roof.setdefault("traffic", None)
-    out["roofline"] = roof
+    if resident:
+        out["roofline"] = {"bound": "latency", "frac": None, "traffic": None, "per": "GPU",
+                           "kernel": f"resident_kernel<{M}, {K}, ...> on rank 0's {fl} bins: the whole iteration in one persistent launch",
+                           "note": "X stays in registers + LDS for the whole launch; what bounds the iteration is the dependency chain "
+                                   "power -> (exchange) -> r -> V -> W across workgroups and GPUs (per_rank_stage_ms)"}
+        out["config"]["parallelism"] = (f"bins sharded over {world} GPU(s); X-resident persistent kernel per rank, the partial source powers "
+                                        "exchanged inside it by peer stores over xGMI (no collective in the loop)")
+    else:
+        _, roof = _cov_roofline((T, fl, M, K), args.precision, cov_ms)
+        roof["kernel"] += f" on rank 0's {fl} bins"
+        roof["per"] = "GPU"
+        roof.setdefault("traffic", None)
+        out["roofline"] = roof
     out["cpu_baseline"] = None      # reported at N = 1 only
-    out["ranks"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "exchange": exchange_name,
-                    "exchange_requested": args.exchange, "fallback": exchange_fallback,
+    out["ranks"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "exchange": "resident" if resident else exchange_name,
+                    "exchange_requested": args.exchange, "fallback": resident_refused or exchange_fallback,
                     "per_rank_stage_ms": gathered, "message_bytes_per_rank": int(p_local.numel() * 4)}
     dist.destroy_process_group()
     dog.cancel()
@@ -604,7 +638,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=4, help="extra measurements of the same K steps for value_median (N = 1)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="headline",
                     help="headline: BASELINE.json configs[2] (the metric's workload); cfg5: configs[4], 16 mics / 16 sources; "
-                         "cfg2: configs[1]; shard8: one rank's shard of configs[3]")
+                         "cfg2: configs[1]; shard8: one rank's shard of configs[3]; tiny: test-only")
     ap.add_argument("--precision", choices=list(MODES), default=None,
                     help="arithmetic of the timed run (default: what overiva() runs on this input -- mixed up to 8 channels, "
                          "precise for 9..16); the other modes are timed too")
@@ -614,9 +648,10 @@ def main():
     ap.add_argument("--no-other-mode", action="store_true", help="do not also time the other arithmetic modes")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (exercises RCCL + graph capture on 1 GPU)")
-    ap.add_argument("--exchange", choices=["collective", "push"], default=os.environ.get("OIVA_EXCHANGE", "collective"),
-                    help="all-gather of the partial powers when sharded: torch.distributed's collective (RCCL, default) or the "
-                         "library's push exchange (opt-in; validated at start-up, falls back to the collective)")
+    ap.add_argument("--exchange", choices=["collective", "push", "resident"], default=os.environ.get("OIVA_EXCHANGE", "collective"),
+                    help="exchange of the partial powers when sharded: torch.distributed's collective (RCCL, default), the "
+                         "library's push exchange (opt-in; validated at start-up, falls back to the collective), or inside the "
+                         "X-resident kernel (opt-in; needs every rank's shard to fit on chip, else the collective)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the sharded path (nccl = RCCL; tests use gloo)")
     ap.add_argument("--single-device", action="store_true",
                     help="tests on a 1-GPU box: every rank uses GPU 0 (needs --backend gloo: RCCL refuses two ranks on one device)")

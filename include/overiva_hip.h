@@ -248,6 +248,9 @@ int oiva_plan_resident_debug(oiva_plan *p, int timeout_ms, int stall_block);
  * (F < F_total).  Every rank must call oiva_plan_iterate with the same counts.  A launch that gives up returns
  * OIVA_ERR_STATE (nothing written).  x = NULL disconnects. */
 int oiva_plan_resident_connect(oiva_plan *p, struct oiva_xchg *x);
+/* Number of frame splits of the resident grid (0: the library's choice).  The ranks of a sharded run must use one
+ * geometry: they agree on the smallest count any of them chose (uneven shards).  Call it while resident is off. */
+int oiva_plan_set_resident_splits(oiva_plan *p, int nsplit);
 
 /*
  * Test-only stage access (per-kernel parity tests call these through the same ABI).

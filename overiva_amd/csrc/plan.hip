@@ -513,7 +513,7 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     choose_cov_geom(p, 0);
     choose_pow_geom(p, 0);
     choose_stats_geom(p);
-    p->res_ok = resident_geometry(T, F, M, K, p->n_cu, &p->rg);
+    p->res_ok = resident_geometry(T, F, M, K, p->n_cu, 0, &p->rg);
     const size_t nTK = (size_t)T * K;
     const size_t nFMM = (size_t)F * M * M;
     hipError_t e = hipSuccess;
@@ -1018,6 +1018,23 @@ int oiva_plan_set_resident(oiva_plan* p, int enable) {
     int rc = resident_alloc(p);
     if (rc) return rc;
     p->res_on = true;
+    return OIVA_OK;
+}
+
+int oiva_plan_set_resident_splits(oiva_plan* p, int nsplit) {
+    NEED(p && nsplit >= 0, OIVA_ERR_ARG, "bad arguments");
+    NEED(!p->res_on, OIVA_ERR_STATE, "switch the resident iteration off before changing its geometry");
+    DeviceGuard guard(p->device);
+    ResidentGeom g;
+    const bool ok = resident_geometry(p->T, p->F, p->M, p->K, p->n_cu, nsplit, &g);
+    NEED(ok || nsplit == 0, OIVA_ERR_ARG, "the shape does not fit on chip with that many frame splits");
+    if (p->res_block) {                        // buffers were sized for the old geometry
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipFree(p->res_block));
+        p->res_block = nullptr;
+    }
+    p->res_ok = ok;
+    if (ok) p->rg = g;
     return OIVA_OK;
 }
 

@@ -49,7 +49,8 @@ struct ResidentArgs {
 constexpr int kResidentStamps = 10;
 
 // true when the shape can run resident on a chip of n_cu compute units (fills g)
-bool resident_geometry(int T, int F, int M, int K, int n_cu, ResidentGeom* g);
+// ns_req > 0 asks for that many frame splits (at most what the chip holds); the result may have fewer when TW rounds up
+bool resident_geometry(int T, int F, int M, int K, int n_cu, int ns_req, ResidentGeom* g);
 hipError_t launch_resident(hipStream_t s, const ResidentArgs& a, int M, int K, bool update_f64);
 // per-shape instantiations (kernels_resident_m4.hip, kernels_resident_m8.hip)
 hipError_t launch_resident_m4(hipStream_t s, const ResidentArgs& a, int K, bool update_f64);

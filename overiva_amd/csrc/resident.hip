@@ -5,7 +5,7 @@ namespace oiva {
 
 // Workgroup (g, c) keeps 16 bins x TW frames on chip; the grid NB x NS must be resident as a whole, one workgroup
 // per compute unit (each one takes most of a CU's LDS and, with JR > 0, all of its registers).
-bool resident_geometry(int T, int F, int M, int K, int n_cu, ResidentGeom* out) {
+bool resident_geometry(int T, int F, int M, int K, int n_cu, int ns_req, ResidentGeom* out) {
     if (!(M == 4 || M == 8) || !(K == 1 || K == 2) || K >= M) return false;   // structured update: 1 or 2 sources + background
     ResidentGeom g;
     g.NB = (F + 15) / 16;
@@ -16,6 +16,10 @@ bool resident_geometry(int T, int F, int M, int K, int n_cu, ResidentGeom* out) 
     int ns = n_cu / g.NB;
     ns = std::min(ns, 32);                                   // the update adds the NS partials of its bin: one or two rounds of loads
     ns = std::min(ns, std::max(1, T / 16));
+    if (ns_req > 0) {                                        // the ranks of a sharded run agree on one split count
+        if (ns_req > ns) return false;
+        ns = ns_req;
+    }
     if (ns < 1) return false;
     g.TW = ((T + ns - 1) / ns + 15) / 16 * 16;
     g.NS = (T + g.TW - 1) / g.TW;

@@ -246,6 +246,9 @@ class Plan:
         _lib.check(self.lib.oiva_plan_resident_phases(self.h, arr, C.byref(n)))
         return dict(zip(self.RESIDENT_PHASES, list(arr))), n.value
 
+    def set_resident_splits(self, nsplit=0):
+        _lib.check(self.lib.oiva_plan_set_resident_splits(self.h, int(nsplit)))
+
     def resident_connect(self, xchg_handle):
         """bins sharded over GPUs: the connected exchange (``exchange.PushExchange.h``) the resident kernel pushes its
         rank's partial powers through; None disconnects"""

@@ -21,8 +21,10 @@ _active = None  # (group,) when overiva() should shard
 def enable_bin_sharding(group=None, exchange=None):
     """Make ``overiva()`` shard bins over the ranks of ``group`` (default: the world group).
     Every rank must then call ``overiva()`` with the same arguments; every rank gets the full result.
-    ``exchange``: "collective" (torch.distributed all-gather, the default) or "push" (the library's own exchange,
-    validated against the collective before use; see exchange.py); None reads $OIVA_EXCHANGE."""
+    ``exchange``: "collective" (torch.distributed all-gather, the default), "push" (the library's own exchange,
+    validated against the collective before use; see exchange.py) or "resident" (the X-resident kernel with the exchange
+    of the partial powers inside it, where every rank's shard fits on chip: ``BinShardedSolver``); None reads
+    $OIVA_EXCHANGE."""
     import torch.distributed as dist
 
     if not dist.is_initialized():
@@ -112,6 +114,66 @@ class HipEngine:
     def set_w_eig(self):
         self.plan.set_w_eig()
 
+    def setup_resident(self, dist, group, rank, world):
+        """The X-resident kernel for this rank's shard, exchanging the partial source powers between the ranks itself
+        (csrc/resident_kernel.inc).  Every rank's shard must qualify with the same frame-split geometry; the ranks agree
+        on that (and on the mapping of each other's gather buffers) before anything is switched on.  Returns the reason it
+        was NOT switched on, or None."""
+        info = self.plan.resident_info()
+        alls = [None] * world
+        dist.all_gather_object(alls, (bool(info["qualifies"]), info["frame_splits"]), group=group)
+        if not all(a[0] for a in alls):
+            return "shard does not fit on chip on rank(s) " + ", ".join(str(r) for r, a in enumerate(alls) if not a[0])
+        ns = min(a[1] for a in alls)           # uneven shards choose different split counts: the smallest fits everybody
+        try:
+            self.plan.set_resident_splits(ns)
+            info = self.plan.resident_info()
+            mine = (bool(info["qualifies"]), info["frame_splits"], info["frames_per_split"])
+        except ValueError as e:
+            mine = (False, 0, 0)
+        dist.all_gather_object(alls, mine, group=group)
+        if not all(a[0] for a in alls) or len({a[1:] for a in alls}) != 1:
+            return f"the ranks found no common frame-split geometry: {alls}"
+        if world == 1:
+            self.plan.set_resident(True)
+            return None
+        from .exchange import PushExchange
+
+        x, ok, why, mineh = None, True, "", b"\0" * 64
+        try:
+            x = PushExchange(self.device.index, rank, world, 0, info["frame_splits"] * info["frames_per_split"] * self.K * 4,
+                             self.stream.cuda_stream)
+            mineh = x.handle()
+        except Exception as e:
+            ok, why = False, f"{type(e).__name__}: {e}"
+        hs = [None] * world
+        dist.all_gather_object(hs, (ok, mineh, why), group=group)
+        if all(h[0] for h in hs):
+            try:
+                x.connect([h[1] for h in hs])
+                self.plan.resident_connect(x.h)
+            except Exception as e:
+                ok, why = False, f"{type(e).__name__}: {e}"
+        else:
+            ok = False
+            why = why or "; ".join(f"rank {r}: {h[2]}" for r, h in enumerate(hs) if not h[0])
+        vs = [None] * world
+        dist.all_gather_object(vs, (ok, why), group=group)
+        if not all(v[0] for v in vs):
+            try:
+                self.plan.resident_connect(None)
+            except Exception:
+                pass
+            if x is not None:
+                x.close()
+            return "; ".join(f"rank {r}: {v[1]}" for r, v in enumerate(vs) if not v[0])
+        self.resident_xchg = x
+        self.plan.set_resident(True)
+        return None
+
+    def iterate_resident(self, n):
+        self.plan.iterate(n)
+
     def power(self):
         self.plan.power()
 
@@ -135,6 +197,9 @@ class HipEngine:
 
     def close(self):
         self.plan.close()
+        if getattr(self, "resident_xchg", None) is not None:
+            self.resident_xchg.close()
+            self.resident_xchg = None
 
 
 class BinShardedSolver:
@@ -166,10 +231,23 @@ class BinShardedSolver:
         self.nparts = self.world * ppr
         # transport of the per-iteration all-gather: torch.distributed's collective, or the library's push exchange
         # when asked for and validated (exchange.py)
+        # "resident": one persistent launch per iterate() call with the shard on chip and the exchange inside the kernel;
+        # agreed between the ranks, and off (with the reason kept) where a shard does not qualify
+        import os
+
+        want = exchange or os.environ.get("OIVA_EXCHANGE", "collective")
+        choice = [want]
+        dist.broadcast_object_list(choice, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        want = choice[0]
+        self.resident, self.resident_refused = False, None
+        if want == "resident" and hasattr(self.engine, "setup_resident") and precision != "precise":
+            self.resident_refused = self.engine.setup_resident(dist, group, self.rank, self.world)
+            self.resident = self.resident_refused is None
         if hasattr(self.engine, "plan"):
             from .exchange import make_exchange
 
-            self.xchg = make_exchange(self.engine, dist, group, self.rank, self.world, self.p_local, self.p_all, prefer=exchange)
+            self.xchg = make_exchange(self.engine, dist, group, self.rank, self.world, self.p_local, self.p_all,
+                                      prefer="collective" if want == "resident" else want)
         else:
             self.xchg = None
 
@@ -200,6 +278,21 @@ class BinShardedSolver:
             self.set_w(eig_init(self.get_cx(), self.K))
 
     def iterate(self, n):
+        if self.resident:
+            # every rank launches the same n iterations; a launch that gave up (a rank's parts did not arrive) leaves W
+            # unchanged on that rank only, so the ranks compare notes before anybody goes on
+            try:
+                with self.engine.stream_ctx():
+                    self.engine.iterate_resident(n)
+                mine = None
+            except RuntimeError as e:
+                mine = str(e)
+            notes = [None] * self.world
+            self.dist.all_gather_object(notes, mine, group=self.group)
+            if any(m is not None for m in notes):
+                raise RuntimeError("X-resident sharded iteration failed: " +
+                                   "; ".join(f"rank {r}: {m}" for r, m in enumerate(notes) if m is not None))
+            return
         with self.engine.stream_ctx():
             for _ in range(n):
                 self.engine.power()                                # local sum_f |y|^2 -> p_local
@@ -226,6 +319,12 @@ class BinShardedSolver:
         return W
 
     def close(self):
+        import sys
+
+        _ov = sys.modules[__package__ + ".overiva"]      # (the package attribute `overiva` is the function, not the module)
+        _ov._last_info = {"sharded": True, "world": self.world, "resident": getattr(self, "resident", False),
+                          "resident_refused": getattr(self, "resident_refused", None),
+                          "exchange": "resident" if getattr(self, "resident", False) else getattr(self.xchg, "name", None)}
         if getattr(self, "xchg", None) is not None:
             self.engine.sync()
             self.xchg.close()

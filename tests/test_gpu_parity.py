@@ -652,6 +652,75 @@ def test_headline_size_properties(oa):
     # test_activation at small sizes; here only its normalisation is checked (above).
 
 
+@pytest.mark.parametrize("mode", ["fast", "precise"])
+def test_cfg5_full_size_properties(oa, mode):
+    """2048 bins x 4000 frames x 16 mics / 16 src (BASELINE.json configs[4]) at FULL size -- the geometry bench.py times
+    (frame splits of the matrix-core covariance pass, the MFMA power pass, one wavefront per bin over 2048 bins in the
+    16 x 16 update): invariants that need no oracle, plus the covariances of three bins against the oracle"""
+    T, F, M, K = 4000, 2048, 16, 16
+    X = orc.synth_iid(T, F, M, seed=2)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision(mode)
+        p.set_x(X)
+        p.covariance()
+        p.set_w(None)
+        p.iterate(2)
+        rinv, wscale = p.t_get_rinv()
+        What = p.t_get_what(np.complex128)
+        V = p.t_get_v(np.complex128)                       # covariances of the last iteration, (K, F, M, M)
+        W = p.get_w()
+    assert np.all(np.isfinite(W)) and W.shape == (F, M, K)
+    # mean_t r = 1 before the eps floor (overiva.py:158-159), every source
+    assert abs(np.mean(1.0 / rinv.astype(np.float64), axis=0) - 1.0).max() < 1e-5
+    # w_s^H V_s w_s = 1 for the last-updated source (overiva.py:185-186), every bin
+    s = K - 1
+    w = What[:, :, s]
+    q = np.einsum("fc,fcd,fd->f", np.conj(w), V[s], w)
+    assert np.abs(q - 1.0).max() < (1e-4 if mode == "fast" else 1e-9)
+    # V Hermitian
+    assert np.abs(V[s] - np.conj(np.swapaxes(V[s], 1, 2))).max() < 1e-6 * np.abs(V[s]).max()
+    # the covariances of three bins, all 16 sources, against the oracle given the device's own weights
+    tol = 5e-6 if mode == "fast" else 1e-6      # (the weights travel as float32 in both modes)
+    for f in (0, 1023, 2047):
+        ref = orc.weighted_cov_all(X[:, f:f + 1, :], rinv.astype(np.float64))[:, 0]
+        assert orc.rel_err(V[:, f], ref) < tol
+
+
+@pytest.fixture(scope="module")
+def headline_mixture():
+    """2048 x 4000 x 8 / 2 mixture-like input and the oracle's results after 20 iterations: the reference's own arithmetic
+    for complex64 input (reference-faithful form) and its complex128 result (about a minute of CPU work, shared)"""
+    T, F, M, K = 4000, 2048, 8, 2
+    X = orc.synth_mixture(T, F, M, K, seed=21)
+    _, W64 = orc.overiva_faithful(X, n_src=K, n_iter=20, proj_back=False, return_filters=True)
+    _, W128 = orc.overiva_staged(X.astype(np.complex128), n_src=K, n_iter=20, proj_back=False, return_filters=True)
+    return X, W64, W128
+
+
+@pytest.mark.parametrize("mode", ["mixed", "fast", "precise"])
+def test_headline_mixture_20_iterations(oa, headline_mixture, mode):
+    """the headline shape (BASELINE.json configs[2]) on ill-conditioned mixture-like input for 20 iterations, every
+    arithmetic mode, against the reference's own complex64 arithmetic (oracle, reference-faithful form): as close to it as
+    its distance from the complex128 result (the floor) allows"""
+    X, W64, W128 = headline_mixture
+    K = 2
+    floor = orc.rel_err(W64, W128)
+    oa.set_precision(mode)
+    try:
+        Y, W = oa.overiva(X, n_src=K, n_iter=20, proj_back=False, return_filters=True)
+    finally:
+        oa.set_precision("auto")
+    e64, e128 = orc.rel_err(W, W64), orc.rel_err(W, W128)
+    eY = orc.rel_err(Y, _demix(X, W128))
+    _log(test="headline20", fixture="T4000F2048M8K2 mixture", model="laplace", n_iter=20, input="c64", mode=mode, W_vs_c128=e128,
+         Y_vs_c128=eY, W_vs_ref_c64=e64, ref_c64_floor=floor)
+    print(f"\n[parity] headline mixture 20 its {mode}: W vs reference-c64 {e64:.2e} (floor {floor:.2e}), vs c128 {e128:.2e}, Y {eY:.2e}")
+    if mode == "fast":
+        assert e128 < max(TOL, FAST_FLOORS * floor)
+    else:
+        assert e64 < max(TOL, 1.5 * floor) and e128 < max(TOL, floor) and eY < max(TOL, floor)
+
+
 def test_plain_c_program_runs(oa, tmp_path):
     """examples/c_abi_demo.c: the C ABI driven from plain C on the GPU"""
     import os

@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, world, T, F, M, K, model, precision, n_iter, port, exchange="collective", init="eye"):
+def _run(tmp_path, world, T, F, M, K, model, precision, n_iter, port, exchange="collective", init="eye", backend="gloo", data="mixture"):
     out = str(tmp_path / f"sharded_{world}.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "tests", "helpers", "sharded_worker.py"), out, str(T), str(F), str(M),
-           str(K), model, precision, str(n_iter), exchange, init]
+           str(K), model, precision, str(n_iter), exchange, init, backend, data]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -72,6 +72,57 @@ def test_sharded_init_eig_runs_on_every_ranks_device(tmp_path):
     assert np.array_equal(got["W"], W) and np.array_equal(got["Y"], Y)
 
 
+def test_resident_shard_through_an_rccl_group(tmp_path):
+    """one rank's shard of the headline shape at 8 GPUs (256 x 4000 x 8 / 2) through the bin-sharded driver over a REAL
+    RCCL process group (backend nccl, world = 1: what this 1-GPU box can hold) with the X-resident kernel: callbacks,
+    projection back and the gathers of the sharded path around one persistent launch per 10 iterations; against the
+    single-process drop-in call"""
+    import overiva_amd as oa
+    from oracle import overiva_oracle as orc
+
+    T, F, M, K, n_iter = 4000, 256, 8, 2, 12
+    got = _run(tmp_path, 1, T, F, M, K, "laplace", "mixed", n_iter, 29641, "resident", "eye", "nccl", "iid")
+    assert str(got["backend"]) == "nccl" and int(got["world"]) == 1 and bool(got["resident"]), str(got["refused"])
+    X = orc.synth_iid(T, F, M, seed=11)
+    oa.set_precision("mixed")
+    try:
+        seen = []
+        Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, return_filters=True, callback=lambda y: seen.append(y.copy()))
+    finally:
+        oa.set_precision("auto")
+    assert oa.last_solver_info()["resident_launches"] >= 2
+    assert np.array_equal(got["W"], W) and np.array_equal(got["Y"], Y) and np.array_equal(got["cb"], np.stack(seen))
+    _, Wr = orc.overiva_staged(X.astype(np.complex128), n_src=K, n_iter=n_iter, proj_back=False, return_filters=True)
+    assert orc.rel_err(W, Wr) < 1e-5
+
+
+@pytest.mark.parametrize("world,F", [(2, 128), (3, 192)])
+def test_resident_exchange_between_processes_sharing_one_gpu(tmp_path, world, F):
+    """the exchange INSIDE the X-resident kernel with real processes: every rank's persistent kernel stores its column sums
+    into every rank's gather buffer (IPC-mapped fine-grained memory; across GPUs these stores travel over xGMI) and waits for
+    the others' -- here the ranks' kernels share the one GPU of the box, small enough to be resident side by side.  Same
+    result as the four-launch path in one process (to rounding: gamma is applied after the sums, the parts lose one
+    mantissa bit to the epoch tag)."""
+    import overiva_amd as oa
+    from oracle import overiva_oracle as orc
+
+    T, M, K, n_iter = 300, 4, 2, 12
+    got = _run(tmp_path, world, T, F, M, K, "laplace", "mixed", n_iter, 29650 + world, "resident")
+    assert int(got["world"]) == world and bool(got["resident"]), str(got["refused"])
+    oa.set_precision("mixed")
+    os.environ["OIVA_RESIDENT"] = "0"
+    try:
+        X = orc.synth_mixture(T, F, M, K, seed=11)
+        seen = []
+        Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, return_filters=True, callback=lambda y: seen.append(y.copy()))
+    finally:
+        oa.set_precision("auto")
+        os.environ.pop("OIVA_RESIDENT", None)
+    eW, eY = orc.rel_err(got["W"], W), orc.rel_err(got["Y"], Y)
+    print(f"\n[resident, {world} processes] W {eW:.1e} Y {eY:.1e}")
+    assert eW < 2e-5 and eY < 2e-5 and got["cb"].shape == np.stack(seen).shape
+
+
 @pytest.mark.parametrize("exchange", ["collective", "push"])
 def test_bench_two_ranks_on_one_gpu(exchange):
     """bench.py's N > 1 path with two real ranks (both on GPU 0, gloo transport): one JSON line from rank 0, as the last
@@ -91,3 +142,23 @@ def test_bench_two_ranks_on_one_gpu(exchange):
     ranks = d["ranks"]["per_rank_stage_ms"]
     assert d["ranks"]["exchange"] == exchange
     assert [x["rank"] for x in ranks] == [0, 1] and ranks[0]["bins"] == [0, 1024] and ranks[1]["bins"] == [1024, 2048]
+
+
+def test_bench_starts_its_own_ranks_and_runs_the_resident_exchange():
+    """`python bench.py --gpus 2` WITHOUT a launcher (no WORLD_SIZE): the ranks are children started before any GPU call, the
+    parent relays rank 0's line.  A shape small enough for the two ranks' persistent kernels to be resident side by side on
+    the box's one GPU (one workgroup per CU each), the exchange inside the X-resident kernels"""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "20", "--warmup", "3",
+           "--backend", "gloo", "--single-device", "--exchange", "resident", "--launch-timeout", "150"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["launcher"]["spawned_ranks"] == 2 and d["launcher"]["attempts"][-1]["status"] == "ok"
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0
+    assert d["ranks"]["exchange"] == "resident" and d["ranks"]["fallback"] is None, (d["ranks"], d["launcher"], r.stderr[-3000:])
+    assert len(d["ranks"]["per_rank_stage_ms"]) == 2 and "resident_phase_us_workgroup0" in d["ranks"]["per_rank_stage_ms"][0]
