@@ -223,7 +223,8 @@ def _cov_roofline(shape, mode, cov_ms):
                    "frac": issued / (cov_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                    "issued_flops_per_launch": issued, "naive_complex_flops_per_launch": naive,
                    "naive_complex_tflops": naive / (cov_ms * 1e-3) / 1e12, "avg_launch_ms": cov_ms,
-                   "note": "achieved/frac count ISSUED matrix-core flops; the naive-complex figure is algorithmic speed only"}
+                   "note": "achieved/frac count ISSUED matrix-core flops; the naive-complex figure is algorithmic speed only; "
+                           "avg_launch_ms is the event-bracketed stage (weights pre-pass of ~6 us + the matrix-core kernel)"}
 
 
 def _secondary_config(torch, oa, dev, name, args):

@@ -82,6 +82,7 @@ SIGNATURES = {
     "oiva_plan_resident_phases": [_vp, C.POINTER(C.c_double), C.POINTER(_i)],
     "oiva_plan_resident_debug": [_vp, _i, _i],
     "oiva_plan_resident_connect": [_vp, _vp],
+    "oiva_plan_resident_trace": [_vp, _i, _vp, C.POINTER(_i), C.POINTER(_i)],
     "oiva_plan_set_resident_splits": [_vp, _i],
     "oiva_test_set_rinv": [_vp, _vp],
     "oiva_test_get_rinv": [_vp, _vp, _vp],

@@ -38,7 +38,8 @@ struct ResidentArgs {
     // memory, [2 (epoch parity)][world][NS * TW][K] sums of the ranks' parts; every rank must run the same NS x TW
     float* gath[OIVA_XCHG_MAX_RANKS];
     int rank, world;
-    unsigned long long* stamps;   // [n_iter][kResidentStamps] 100 MHz timestamps of workgroup 0, or nullptr
+    unsigned long long* stamps;   // [n_iter][kResidentStamps] 100 MHz timestamps of workgroup 0 (stamp_all: [workgroup][n_iter][..]), or nullptr
+    int stamp_all;          // every workgroup records its timestamps (tools/exp_resident_trace.py)
     int T, F, F_total, model;
     ResidentGeom g;
     int n_iter;

@@ -254,6 +254,17 @@ class Plan:
         rank's partial powers through; None disconnects"""
         _lib.check(self.lib.oiva_plan_resident_connect(self.h, xchg_handle))
 
+    def resident_trace(self, enable=True, fetch=False):
+        """diagnostics: record every workgroup's timestamps in the next launches (<= 64 iterations); with ``fetch`` returns the
+        last launch's (n_wg, n_iter, 10) array of 100 MHz ticks"""
+        nw, ni = C.c_int(), C.c_int()
+        _lib.check(self.lib.oiva_plan_resident_trace(self.h, 1 if enable else 0, None, C.byref(nw), C.byref(ni)))
+        if not fetch or ni.value == 0:
+            return None
+        out = np.zeros((nw.value, ni.value, 10), np.uint64)
+        _lib.check(self.lib.oiva_plan_resident_trace(self.h, 1 if enable else 0, _lib.ptr(out), C.byref(nw), C.byref(ni)))
+        return out
+
     def resident_debug(self, timeout_ms=0, stall_block=-1):
         _lib.check(self.lib.oiva_plan_resident_debug(self.h, int(timeout_ms), int(stall_block)))
 

@@ -33,8 +33,13 @@ def main():
 
     warnings.simplefilter("error")                    # a fall-back to the collective must fail the test, not pass silently
     seen = []
-    Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, model=model, return_filters=True, init_eig=init_eig,
-                      callback=lambda y: seen.append(y.copy()))
+    if len(sys.argv) > 10 and sys.argv[10] == "pca":        # auxiva_pca under bin sharding (auxiva_pca.py:63-92): Y only
+        Y = oa.auxiva_pca(X, n_src=K, n_iter=n_iter, proj_back=True, model=model)
+        W = np.zeros((1,), X.dtype)
+        seen.append(Y[:1])
+    else:
+        Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, model=model, return_filters=True, init_eig=init_eig,
+                          callback=lambda y: seen.append(y.copy()))
     info = oa.last_solver_info()
     oa.disable_bin_sharding()
     if dist.get_rank() == 0:

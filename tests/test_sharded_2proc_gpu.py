@@ -72,6 +72,24 @@ def test_sharded_init_eig_runs_on_every_ranks_device(tmp_path):
     assert np.array_equal(got["W"], W) and np.array_equal(got["Y"], Y)
 
 
+def test_auxiva_pca_with_sharded_bins(tmp_path):
+    """auxiva_pca() while bin sharding is on: the PCA front end runs on every rank's GPU over all bins, the inner determined
+    solve shards the reduced tensor (a host array: a device-resident tensor cannot be sharded); same result as one process"""
+    import overiva_amd as oa
+    from oracle import overiva_oracle as orc
+
+    T, F, M, K, n_iter = 300, 128, 4, 2, 6
+    got = _run(tmp_path, 2, T, F, M, K, "laplace", "mixed", n_iter, 29633, "collective", "pca")
+    oa.set_precision("mixed")
+    os.environ["OIVA_RESIDENT"] = "0"
+    try:
+        Y = oa.auxiva_pca(orc.synth_mixture(T, F, M, K, seed=11), n_src=K, n_iter=n_iter, proj_back=True, model="laplace")
+    finally:
+        oa.set_precision("auto")
+        os.environ.pop("OIVA_RESIDENT", None)
+    assert got["Y"].shape == Y.shape and orc.rel_err(got["Y"], Y) < 1e-5
+
+
 def test_resident_shard_through_an_rccl_group(tmp_path):
     """one rank's shard of the headline shape at 8 GPUs (256 x 4000 x 8 / 2) through the bin-sharded driver over a REAL
     RCCL process group (backend nccl, world = 1: what this 1-GPU box can hold) with the X-resident kernel: callbacks,
