@@ -392,18 +392,46 @@ def run_sharded(args):
         # all: the X-resident kernel with the exchange inside it (opt-in; every rank's shard must fit on chip)
         from overiva_amd.exchange import make_exchange
 
+        want_resident = args.exchange in ("resident", "auto")
         resident_refused = None
-        if args.exchange == "resident":
+        if want_resident:
             resident_refused = eng.setup_resident(dist, None, rank, world) if args.precision != "precise" else "precise arithmetic"
-            if resident_refused is not None and rank == 0:
-                print(f"[bench] X-resident exchange not used: {resident_refused}; collective", file=sys.stderr)
-        resident = args.exchange == "resident" and resident_refused is None
-        xchg = make_exchange(eng, dist, None, rank, world, p_local, p_all, prefer="collective" if args.exchange == "resident" else args.exchange)
+        xchg = make_exchange(eng, dist, None, rank, world, p_local, p_all, prefer="collective" if want_resident else args.exchange)
         nparts = world * ppr
 
         def step():
             eng.power()
             eng.update_ptr(xchg.gather(), nparts)
+
+        if want_resident and resident_refused is None:
+            # Validate the kernel's own exchange on THIS platform before it is timed: one iteration through it against one
+            # through the collective, from the same start, on every rank.  (A launch whose waits run into their time-outs
+            # returns an error without having written W; whatever happens, W is re-initialised afterwards.)
+            why = None
+            try:
+                eng.plan.set_resident(False)
+                step()
+                stream.synchronize()
+                w_coll = eng.get_w()
+                eng.set_w(None)
+                eng.plan.set_resident(True)
+                eng.plan.iterate(1)
+                w_res = eng.get_w()
+                err = float(np.linalg.norm(w_res - w_coll) / max(np.linalg.norm(w_coll), 1e-30))
+                if not err < 1e-4:
+                    why = f"one iteration differs from the collective path by {err:.1e}"
+            except Exception as e:
+                why = f"{type(e).__name__}: {e}"
+            notes = [None] * world
+            dist.all_gather_object(notes, why)
+            if any(n is not None for n in notes):
+                resident_refused = "validation failed: " + "; ".join(f"rank {r}: {n}" for r, n in enumerate(notes) if n is not None)
+                eng.plan.set_resident(False)
+            eng.set_w(None)
+            stream.synchronize()
+        if want_resident and resident_refused is not None and rank == 0:
+            print(f"[bench] X-resident exchange not used: {resident_refused}; collective", file=sys.stderr)
+        resident = want_resident and resident_refused is None
 
         graph = None
         if resident:
@@ -598,7 +626,7 @@ def launch_ranks(args, argv, script=None):
     children's process group is killed.  An attempt with the push exchange that fails or times out is repeated with the
     collective, in fresh processes."""
     attempts = []
-    exchanges = [args.exchange] + (["collective"] if args.exchange != "collective" else [])
+    exchanges = [args.exchange] + (["collective"] if args.exchange != "collective" else [])      # second attempt: the plain collective
     base = _strip_option(argv, "--exchange")
     for ex in exchanges:
         port = _free_port()
@@ -649,10 +677,11 @@ def main():
     ap.add_argument("--no-other-mode", action="store_true", help="do not also time the other arithmetic modes")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (exercises RCCL + graph capture on 1 GPU)")
-    ap.add_argument("--exchange", choices=["collective", "push", "resident"], default=os.environ.get("OIVA_EXCHANGE", "collective"),
-                    help="exchange of the partial powers when sharded: torch.distributed's collective (RCCL, default), the "
-                         "library's push exchange (opt-in; validated at start-up, falls back to the collective), or inside the "
-                         "X-resident kernel (opt-in; needs every rank's shard to fit on chip, else the collective)")
+    ap.add_argument("--exchange", choices=["auto", "collective", "push", "resident"], default=os.environ.get("OIVA_EXCHANGE", "auto"),
+                    help="exchange of the partial powers when sharded.  auto (default): inside the X-resident kernel where every "
+                         "rank's shard fits on chip (the headline shape at 8 GPUs) AND one iteration through it reproduces the "
+                         "collective path on this platform, else torch.distributed's collective (RCCL); collective; push: the "
+                         "library's push exchange (validated at start-up, falls back to the collective); resident: as auto")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the sharded path (nccl = RCCL; tests use gloo)")
     ap.add_argument("--single-device", action="store_true",
                     help="tests on a 1-GPU box: every rank uses GPU 0 (needs --backend gloo: RCCL refuses two ranks on one device)")

@@ -46,7 +46,7 @@ def _fake_worker(tmp_path, body):
 
 
 def _launch_args(**kw):
-    d = dict(gpus=2, exchange="collective", launch_timeout=20, launch_grace=2)
+    d = dict(gpus=2, exchange="collective", launch_timeout=20, launch_grace=2)      # (bench.py defaults to --exchange auto)
     d.update(kw)
     return types.SimpleNamespace(**d)
 
