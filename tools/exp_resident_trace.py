@@ -18,7 +18,7 @@ p.iterate(n); p.sync()
 p.resident_trace(True)
 p.iterate(n); p.sync()
 st = p.resident_trace(True, fetch=True).astype(np.int64)       # (wg, iter, 10)
-print("passes over the parts payload (workgroups x iterations): mean %.2f, max %d" % (st[:, 2:, 9].mean(), st[:, 2:, 9].max()))
+
 info = p.resident_info()
 NS = info["frame_splits"]
 names = ["start", "power", "parts", "activation", "cov_acc", "cov_reduce", "partials", "update", "wait_w"]
