@@ -48,6 +48,9 @@ CONFIGS = {
     "cfg5": dict(T=4000, F=2048, M=16, K=16, name="determined AuxIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[4])"),
     "cfg2": dict(T=1000, F=513, M=4, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[1])"),
     "shard8": dict(T=4000, F=256, M=8, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64: one rank's shard of the headline shape at 8 GPUs (BASELINE.json configs[3])"),
+    # not a BASELINE config: 16 channels with few sources, the shape the four-lanes-per-(bin, frame) covariance kernel
+    # (csrc/kernels_cov_quad.hip) exists for; timed in its default arithmetic (`mixed`)
+    "m16k2": dict(T=4000, F=2048, M=16, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (16 channels, few sources)"),
     # test-only: small enough for the X-resident kernels of two ranks to be resident side by side on ONE GPU
     # (tests/test_sharded_2proc_gpu.py); not a BASELINE config
     "tiny": dict(T=600, F=128, M=4, K=2, name="test shape {F} bins x {T} frames x {M} mics / {K} src"),
@@ -215,6 +218,15 @@ def _cov_roofline(shape, mode, cov_ms):
         return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, overiva.py:179)",
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms}
+    if m % 2 == 0 and mode != "precise" and (k <= 2 or (k <= 4 and mode == "mixed")):
+        # the Hermitian half on the vector ALU, four lanes per (bin, frame): one pass over X per two sources
+        bytes_cov = cov_algorithmic_bytes(t, f, m, k) + (-(-k // 2) - 1) * 8 * t * f * m
+        achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
+        kname = f"cov_quad_kernel<{min(k, 2)}, false>"
+        return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance, two sources per pass over X, overiva.py:179)",
+                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
+                       "note": "co-limited by the vector ALU: 512 real FMAs per (bin, frame, source pair) at 16 channels against 128 at 8"}
     naive = 8.0 * k * m * m * t * f            # complex MACs counted as 8 real flops
     issued = 6.0 * k * m * m * t * f           # what the planar form issues: 3 MFMAs of 16x16x4 per 4 frames and source
     kname = "cov_mfma16_kernel<double, 16>" if mode == "precise" else "cov_mfma16_kernel<float, 16>"
@@ -232,7 +244,7 @@ def _secondary_config(torch, oa, dev, name, args):
     shape qualifies, the X-resident kernel; the faster one is `value`"""
     c = CONFIGS[name]
     shape = (c["T"], c["F"], c["M"], c["K"])
-    mode = "mixed" if c["M"] <= 8 else args.cfg5_precision
+    mode = "mixed" if c["M"] <= 8 or name == "m16k2" else args.cfg5_precision
     X = synth_x_device(torch, dev, 0, c["F"], shape[:3])
     torch.cuda.synchronize()
     out = {"workload": c["name"].format(**c), "precision": mode, "steps": args.steps, "warmup": args.warmup}
@@ -328,7 +340,7 @@ def run_single(args):
     torch.cuda.empty_cache()
     if not args.no_configs and args.config == "headline":
         out["configs"] = {}
-        for name in ("cfg2", "shard8", "cfg5"):
+        for name in ("cfg2", "shard8", "cfg5", "m16k2"):
             try:
                 out["configs"][name] = _secondary_config(torch, oa, dev, name, args)
             except Exception as e:  # a secondary shape must not cost the headline line
@@ -663,7 +675,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="0: eager; 1 (default): hipGraph replay on a single GPU, eager when sharded; 2: graph also when sharded")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-configs", action="store_true", help="skip the secondary configs (cfg2, shard8, cfg5) of the N = 1 line")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary configs (cfg2, shard8, cfg5, m16k2) of the N = 1 line")
     ap.add_argument("--repeats", type=int, default=4, help="extra measurements of the same K steps for value_median (N = 1)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="headline",
                     help="headline: BASELINE.json configs[2] (the metric's workload); cfg5: configs[4], 16 mics / 16 sources; "

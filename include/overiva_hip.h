@@ -201,6 +201,11 @@ int oiva_plan_iterate_timed(oiva_plan *p, int n, float *total_ms, float *per_ker
  * get/set the number of frame splits (0 = library default). */
 int oiva_plan_get_cov_splits(oiva_plan *p, int *nsplit);
 int oiva_plan_set_cov_splits(oiva_plan *p, int nsplit);
+/* Which kernel takes the float32 covariance pass of a 10-, 12-, 14- or 16-channel plan with at most 4 sources: 1 (default)
+ * = the vector-ALU kernel that forms the Hermitian half with four lanes per (bin, frame) and writes float64 partial sums
+ * (csrc/kernels_cov_quad.hip), 0 = the planar matrix-core kernel every other 9..16-channel plan uses.  *active (may be
+ * NULL) receives whether the vector-ALU kernel is the one this plan now launches.  Drops captured graphs. */
+int oiva_plan_set_cov_quad(oiva_plan *p, int enable, int *active);
 /* same for the demix+power pass (0 = library default) */
 int oiva_plan_set_pow_splits(oiva_plan *p, int nsplit);
 /* Replay the iteration from a captured hipGraph instead of eager launches (default off). */

@@ -390,6 +390,7 @@ int cov_sources_per_pass(int M, int K, bool f64) {
 
 hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                       void* Vpart, bool f64, int T, int F, int M, int K, const CovGeom& g) {
+    if (M > 8 && g.quad && !f64) return launch_cov_quad(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
     if (M > 8) return launch_cov_mfma(s, X, R, Wt, wscale, model, raw, Vpart, f64, T, F, M, K, g.nsplit, g.tc);
     if (f64 && cov_gram_supported(M)) return launch_cov_gram(s, X, R, wscale, model, raw, Vpart, T, F, M, K, g);
     const int kc = R == nullptr ? 1 : g.kc;

@@ -186,6 +186,11 @@ hipError_t launch_planar(hipStream_t s, const float2* X, const float* Wt, void* 
 
 }  // namespace
 
+hipError_t launch_cov_weights(hipStream_t s, const float* R, float* Wt, float* wscale, int model, int raw, int T, int K, int Kp) {
+    weights_kernel<<<dim3((unsigned)(((long long)T * Kp + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>(R, Wt, wscale, model, raw, T, K, Kp);
+    return hipGetLastError();
+}
+
 hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                            void* Vpart, bool f64, int T, int F, int M, int K, int nsplit, int tc) {
     const bool unit = R == nullptr;
@@ -193,7 +198,8 @@ hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float
     const int Kp = (K + 15) / 16 * 16;      // padded row stride of the weights (scratch holds T * 16 floats)
     if (!unit) {
         if (Wt == nullptr) return hipErrorInvalidValue;
-        weights_kernel<<<dim3((unsigned)(((long long)T * Kp + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>(R, Wt, wscale, model, raw, T, K, Kp);
+        hipError_t e = launch_cov_weights(s, R, Wt, wscale, model, raw, T, K, Kp);
+        if (e != hipSuccess) return e;
     }
     if (f64) return launch_planar<double>(s, X, Wt, Vpart, unit, T, F, M, K, Kp, nsplit, tc);
     return launch_planar<float>(s, X, Wt, Vpart, unit, T, F, M, K, Kp, nsplit, tc);

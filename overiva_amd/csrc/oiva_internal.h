@@ -67,6 +67,7 @@ struct CovGeom {
     int tc;       // frames per split (multiple of 16)
     int kc;       // sources per pass (template KC)
     int nbg;      // bin groups of 16 (grid.x)
+    int quad = 0; // 10/12/14/16 channels, few sources, float32: the vector-ALU kernel of kernels_cov_quad.hip (float64 partials)
 };
 struct PowGeom {
     int nb;       // bin batches of 64 (grid.x)
@@ -97,6 +98,15 @@ hipError_t cov_gram_blocks_per_cu(int kc, int* n);
 //   Wt (T,16): scratch for the final weights (written by a small pre-pass)
 hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                            void* Vpart, bool f64, int T, int F, int M, int K, int nsplit, int tc);
+// vector-ALU kernel for 10, 12, 14, 16 channels and K <= 4 sources, float32 arithmetic (kernels_cov_quad.hip): the Hermitian
+// half split over four lanes per (bin, frame); tc multiple of 8; Vpart float64; R == nullptr: unit weights (K = 1);
+// Wt (T,16): scratch for the final weights, as for launch_cov_mfma
+bool cov_quad_supported(int M, int K);
+int cov_quad_sources_per_pass(int K);
+hipError_t launch_cov_quad(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
+                           double* Vpart, int T, int F, int M, int K, const CovGeom& g);
+// pre-pass of the 9..16-channel kernels: Wt (T, Kp) = 1 / max(r / gamma, eps), columns >= K zero; writes wscale (K)
+hipError_t launch_cov_weights(hipStream_t s, const float* R, float* Wt, float* wscale, int model, int raw, int T, int K, int Kp);
 int cov_sources_per_pass(int M, int K, bool f64);
 hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n);
 bool cov_supported(int M);

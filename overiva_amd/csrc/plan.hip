@@ -74,6 +74,7 @@ struct oiva_plan {
     double* scratch_p = nullptr;   // K*F*M*M packed float64, for getters
 
     CovGeom cov{};
+    bool cov_quad_on = true;      // oiva_plan_set_cov_quad
     CovGeom stg{};              // geometry of the projection-back statistics pass (16-bin groups, independent of cov)
     PowGeom pw{};
     int n_cu = 256;
@@ -88,7 +89,7 @@ struct oiva_plan {
     // element type of the covariance partials: the vector-ALU kernels (<= 8 channels) always sum their float32 lane
     // chains across lanes in float64 and store float64 partials; the 9..16-channel matrix-core kernel stores its
     // accumulator type
-    bool vpart_f64() const { return cov_f64() || M <= 8; }
+    bool vpart_f64() const { return cov_f64() || M <= 8 || cov.quad; }
     int use_graph = 0;
     // OGIVE (ive.py): per-bin state, allocated by oiva_plan_ogive_begin
     OgiveState og{};
@@ -142,6 +143,30 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     g.kc = cov_sources_per_pass(p->M, p->K, p->cov_f64());
     const int nz = ceil_div(p->K, g.kc);
     int nsplit = nsplit_req;
+    // few sources: the Hermitian half on the vector ALU, four lanes per (bin, frame).  One or two sources are one pass
+    // over X and faster than the matrix-core kernel in any mode; three or four are two passes, slower than its float32
+    // form (measured 486-517 against 459 us at 2048 x 4000 x 16) but with float64 partial sums of short float32 chains,
+    // which is what the float64 per-bin algebra of the `mixed` mode needs -- and 1.8 times faster than the float64
+    // matrix-core pass that mode would otherwise have to be replaced by
+    if (p->M > 8 && !p->cov_f64() && p->cov_quad_on && cov_quad_supported(p->M, p->K) && (p->K <= 2 || p->upd_f64())) {
+        // one round of two workgroups per CU
+        g.quad = 1;
+        g.kc = cov_quad_sources_per_pass(p->K);
+        if (nsplit <= 0) {
+            nsplit = std::min(32, pick_splits(p->n_cu * 2, g.nbg * ceil_div(p->K, g.kc), p->T, 128));
+            // only 4 frame phases per workgroup: a lane's float32 chain is T / (4 nsplit) frames, four times that of the
+            // 8-channel kernel at equal splits, and the error of the result grows linearly with it (measured against
+            // the reference's own complex64 floor, 16 channels / 2 sources x 20 iterations: T = 4000: 4 splits 0.8-1.0
+            // floors, 8 splits 0.5-0.6, 16 splits 0.3; T = 163: 1 split 1.4, 4 splits 0.8, 8 splits 0.6).  With the
+            // float64 per-bin algebra (`mixed`, the default arithmetic of these shapes) the chains are what is left of
+            // the error, so that mode takes 8 splits (+18 us on the pass, +8 us in the update at 2048 x 4000 x 16 / 2).
+            if (p->upd_f64()) nsplit = std::max(nsplit, std::min(8, std::max(1, p->T / 8)));
+        }
+        g.tc = round_up(ceil_div(p->T, nsplit), 8);
+        g.nsplit = ceil_div(p->T, g.tc);
+        p->cov = g;
+        return;
+    }
     if (p->M > 8) {
         // planar matrix-core path: one wave per (bin, split); splits bound the length of the fp32
         // accumulation chain (<= 512 frames) and keep >= 2 waves per SIMD when there are few bins
@@ -979,6 +1004,18 @@ int oiva_plan_set_cov_splits(oiva_plan* p, int nsplit) {
     return ensure_vpart(p);
 }
 
+int oiva_plan_set_cov_quad(oiva_plan* p, int enable, int* active) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    int rc = drop_graph(p);
+    if (rc) return rc;
+    p->cov_quad_on = enable != 0;
+    choose_cov_geom(p, 0);
+    if (active) *active = p->cov.quad;
+    return ensure_vpart(p);
+}
+
 int oiva_plan_set_pow_splits(oiva_plan* p, int nsplit) {
     NEED(p, OIVA_ERR_ARG, "null plan");
     NEED(nsplit >= 0 && nsplit <= p->T, OIVA_ERR_ARG, "bad split count");
@@ -1011,7 +1048,8 @@ int oiva_plan_set_precision(oiva_plan* p, int flags) {
         std::vector<double2> wh;
         if ((rc = download_what(p, wh)) || (rc = upload_what(p, wh))) return rc;
     }
-    const bool cov_changed = ((flags ^ p->prec) & OIVA_PREC_COV_F64) != 0;
+    // (more than 8 channels: which float32 kernel takes the pass also depends on the arithmetic of the per-bin algebra)
+    const bool cov_changed = ((flags ^ p->prec) & (OIVA_PREC_COV_F64 | (p->M > 8 ? OIVA_PREC_UPDATE_F64 : 0))) != 0;
     p->prec = flags;
     if (cov_changed) {
         choose_cov_geom(p, 0);            // sources per pass and residency depend on the accumulator type

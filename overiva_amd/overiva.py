@@ -38,14 +38,19 @@ def set_precision(mode):
     _precision = mode
 
 
-def resolve_precision(dtype, n_chan, mode=None):
-    """``"auto"`` follows the reference, which computes in the dtype of X (overiva.py:89,126,131): complex64 input on
-    up to 8 channels -> ``"mixed"``; complex128 input, or 9..16 channels (whose matrix-core covariance pass keeps
-    float32 partial sums) -> ``"precise"``"""
+def resolve_precision(dtype, n_chan, mode=None, n_src=None):
+    """``"auto"`` follows the reference, which computes in the dtype of X (overiva.py:89,126,131): complex128 input ->
+    ``"precise"``; complex64 input -> ``"mixed"`` wherever the covariance pass hands float64 sums of short float32
+    chains to the float64 per-bin algebra: up to 8 channels, and 10 / 12 / 14 / 16 channels with at most 4 sources
+    (csrc/kernels_cov_quad.hip); the other 9..16-channel shapes run the matrix-core pass, whose float32 form keeps
+    float32 partial sums -> ``"precise"``"""
     mode = _precision if mode is None else mode
     if mode != "auto":
         return mode
-    return "mixed" if np.dtype(dtype) == np.complex64 and n_chan <= 8 else "precise"
+    if np.dtype(dtype) != np.complex64:
+        return "precise"
+    n_src = n_chan if n_src is None else n_src
+    return "mixed" if n_chan <= 8 or (n_chan % 2 == 0 and n_chan <= 16 and n_src <= 4) else "precise"
 
 
 def get_precision():
@@ -149,7 +154,7 @@ def overiva(
     if n_iter < 0:
         raise ValueError("n_iter must be >= 0")
 
-    precision = resolve_precision(dtype, n_chan)
+    precision = resolve_precision(dtype, n_chan, n_src=n_src)
     group = sharded.active_group()
     if group is not None and isinstance(X, DeviceX):
         raise ValueError("a device-resident X cannot be sharded over ranks: pass the host array")

@@ -92,6 +92,11 @@ BIG_CASES = [
     ("l", 160, 16, 12, 3),
     ("m", 144, 24, 8, 8),
     ("n", 128, 20, 5, 5),
+    # 10 / 12 / 14 / 16 channels with few sources: the four-lanes-per-(bin, frame) covariance kernel (l above is 12 / 3);
+    # ragged bin groups (F % 16 != 0) and frame counts that are no multiple of the 8-frame step
+    ("o", 163, 19, 16, 2),
+    ("p", 150, 18, 10, 2),
+    ("q", 141, 17, 14, 1),
 ]
 BIG_ITERS = (1, 5, 20)
 
@@ -222,7 +227,10 @@ def main():
 
 def make_big(ref_overiva, ref_pca):
     total = 0
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]      # e.g. --big-only --only=o,p
     for name, T, F, M, K in BIG_CASES:
+        if only and name not in only[0]:
+            continue
         for family in ("iid", "mix"):
             seed = 2000 + ord(name) + (0 if family == "iid" else 500)
             X64 = make_input(family, T, F, M, K, seed)

@@ -1,0 +1,136 @@
+"""The four-lanes-per-(bin, frame) covariance kernel of 10 / 12 / 14 / 16-channel plans with few sources
+(csrc/kernels_cov_quad.hip; reference overiva.py:179 and :87): against the oracle on ragged shapes, against the
+matrix-core kernel it replaces, the rules that select it, the default arithmetic of these shapes, and the full-size
+geometry (2048 bins x 4000 frames x 16 channels / 2 sources) through invariants that need no oracle."""
+import numpy as np
+import pytest
+
+from oracle import overiva_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import overiva_amd
+    from overiva_amd import _lib
+
+    _lib.load()
+    return overiva_amd
+
+
+SHAPES = [(163, 19, 16, 2, "fast"), (150, 18, 10, 2, "fast"), (141, 17, 14, 1, "fast"), (160, 16, 12, 3, "mixed"),
+          (200, 33, 16, 4, "mixed"), (61, 5, 16, 2, "mixed"), (9, 3, 10, 1, "fast"), (35, 40, 12, 2, "fast")]
+
+
+@pytest.mark.parametrize("splits", [0, 1, 3])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(str(v) for v in s))
+def test_quad_covariances_against_oracle(oa, shape, splits):
+    """V_k (overiva.py:179, all sources) and Cx (overiva.py:87): bins that are no multiple of 16, frames that are no
+    multiple of the 8-frame step or fewer than one step, 10 / 12 / 14 channels (entries of channels past M are dropped)"""
+    T, F, M, K, mode = shape
+    X = orc.synth_mixture(T, F, M, K, seed=4)
+    rinv = np.random.default_rng(5).gamma(2.0, 1.0, (T, K)).astype(np.float32)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision(mode)
+        assert p.set_cov_quad(True)
+        if splits:
+            p.set_cov_splits(min(splits, max(1, T // 8)))
+        p.set_x(X)
+        p.covariance()
+        Cx = p.get_cx()
+        p.t_set_rinv(rinv)
+        p.t_run_weighted_cov()
+        V = p.t_get_v(np.complex128)
+    eC = orc.rel_err(Cx, orc.input_covariance(X.astype(np.complex128)))
+    eV = orc.rel_err(V, orc.weighted_cov_all(X, rinv.astype(np.float64)))
+    print(f"\n[quad] {shape} splits={splits}: V {eV:.1e} Cx {eC:.1e}")
+    assert eV < 2e-7 and eC < 2e-7
+    assert np.array_equal(V, np.conj(np.swapaxes(V, -1, -2)))
+
+
+def test_selection_rules(oa):
+    """one or two sources: every float32 mode; three or four: only with the float64 per-bin algebra; never in `precise`,
+    never for odd channel counts or more than four sources; the switch turns it off"""
+    def active(M, K, mode, on=True):
+        with oa.Plan(64, 20, M, K, "laplace") as p:
+            p.set_precision(mode)
+            return p.set_cov_quad(on)
+
+    assert active(16, 2, "fast") and active(10, 1, "fast") and active(14, 2, "mixed")
+    assert active(12, 3, "mixed") and active(16, 4, "mixed")
+    assert not active(12, 3, "fast") and not active(16, 4, "fast")
+    assert not active(16, 2, "precise") and not active(11, 2, "fast") and not active(16, 5, "mixed") and not active(8, 2, "fast")
+    assert not active(16, 2, "fast", on=False)
+    # the precision set AFTER the switch decides as well
+    with oa.Plan(64, 20, 12, 3, "laplace") as p:
+        p.set_precision("fast")
+        assert not p.set_cov_quad(True)
+        p.set_precision("mixed")
+        assert p.set_cov_quad(True)
+        p.set_precision("precise")
+        assert not p.set_cov_quad(True)
+
+
+@pytest.mark.parametrize("shape", [(163, 19, 16, 2), (150, 18, 10, 2), (141, 33, 14, 1)], ids=lambda s: "x".join(str(v) for v in s))
+def test_same_iteration_as_the_matrix_core_kernel(oa, shape):
+    """5 iterations with either covariance kernel under the same float64 per-bin algebra: the two differ only in the
+    rounding of the float32 partial sums"""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F, M, seed=8)
+    W = {}
+    for quad in (True, False):
+        with oa.Plan(T, F, M, K, "laplace") as p:
+            p.set_precision("mixed")
+            assert p.set_cov_quad(quad) == quad
+            p.set_x(X)
+            p.covariance()
+            p.set_w(None)
+            p.iterate(5)
+            W[quad] = p.get_w(np.complex128)
+    e = orc.rel_err(W[True], W[False])
+    print(f"\n[quad] {shape}: W quad vs matrix-core {e:.1e}")
+    assert e < 5e-6
+
+
+def test_default_arithmetic_of_10_to_16_channels(oa):
+    """complex64 input: `mixed` where the kernel applies (even channel counts, at most 4 sources), `precise` elsewhere;
+    complex128 input: `precise`"""
+    rng = np.random.default_rng(0)
+    for (M, K, dt, want) in ((16, 2, np.complex64, "mixed"), (12, 4, np.complex64, "mixed"), (16, 5, np.complex64, "precise"),
+                             (11, 2, np.complex64, "precise"), (16, 2, np.complex128, "precise")):
+        X = (rng.standard_normal((40, 6, M)) + 1j * rng.standard_normal((40, 6, M))).astype(dt)
+        Y = oa.overiva(X, n_src=K, n_iter=2, proj_back=False)
+        assert Y.dtype == dt and oa.last_solver_info()["precision"] == want
+
+
+@pytest.mark.parametrize("mode", ["mixed", "fast"])
+def test_16_channels_2_sources_full_size_properties(oa, mode):
+    """2048 bins x 4000 frames x 16 channels / 2 sources at FULL size -- the geometry the kernel was built for (128 bin
+    groups x 8 or 4 frame splits, 2 workgroups per CU, 1.05 GB of X): invariants that need no oracle, plus the
+    covariances of three bins against the oracle"""
+    T, F, M, K = 4000, 2048, 16, 2
+    X = orc.synth_iid(T, F, M, seed=2)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision(mode)
+        assert p.set_cov_quad(True)
+        p.set_x(X)
+        p.covariance()
+        p.set_w(None)
+        p.iterate(2)
+        rinv, wscale = p.t_get_rinv()
+        What = p.t_get_what(np.complex128)
+        V = p.t_get_v(np.complex128)                       # covariances of the last iteration, (K, F, M, M)
+        W = p.get_w()
+        splits = p.cov_splits()
+    assert splits == (8 if mode == "mixed" else 4)
+    assert np.all(np.isfinite(W)) and W.shape == (F, M, K)
+    assert abs(np.mean(1.0 / rinv.astype(np.float64), axis=0) - 1.0).max() < 1e-5       # overiva.py:158-159
+    s = K - 1
+    w = What[:, :, s]
+    q = np.einsum("fc,fcd,fd->f", np.conj(w), V[s], w)                                  # overiva.py:185-186
+    assert np.abs(q - 1.0).max() < (1e-4 if mode == "fast" else 1e-6)
+    assert np.array_equal(V, np.conj(np.swapaxes(V, -1, -2)))
+    for f in (0, 1023, 2047):
+        ref = orc.weighted_cov_all(X[:, f:f + 1, :], rinv.astype(np.float64))[:, 0]
+        assert orc.rel_err(V[:, f], ref) < 1e-6

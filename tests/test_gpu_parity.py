@@ -225,7 +225,7 @@ def test_overiva_matches_reference(oa, golden, model, n_iter, dt):
     e64 = orc.rel_err(W, golden[k64]) if k64 in golden else None
     from overiva_amd.overiva import resolve_precision
 
-    mode = resolve_precision(Xin.dtype, X.shape[2])
+    mode = resolve_precision(Xin.dtype, X.shape[2], n_src=K)
     if mode == "mixed" and floor is not None:
         b128 = max(b128, floor)                 # never less accurate than the reference's own complex64 arithmetic
     _log(test="e2e", fixture=golden["_id"], model=model, n_iter=n_iter, input=dt, mode=mode, W_vs_c128=e128,

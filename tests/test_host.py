@@ -101,6 +101,20 @@ def test_product_never_imports_the_oracle():
                 assert "import oracle" not in src and "from oracle" not in src, f
 
 
+def test_default_arithmetic_rule():
+    """`auto` (overiva.py:89,126,131: the reference computes in the dtype of X): complex128 -> precise; complex64 -> mixed
+    where the covariance pass hands float64 sums of short float32 chains to the float64 per-bin algebra"""
+    from overiva_amd.overiva import resolve_precision as rp
+
+    assert rp(np.complex128, 4, "auto", 2) == "precise" and rp(np.complex128, 16, "auto", 2) == "precise"
+    assert all(rp(np.complex64, m, "auto", k) == "mixed" for m in range(1, 9) for k in range(1, m + 1))
+    assert all(rp(np.complex64, m, "auto", k) == "mixed" for m in (10, 12, 14, 16) for k in (1, 2, 3, 4))
+    assert all(rp(np.complex64, m, "auto", 5) == "precise" for m in (10, 12, 14, 16))
+    assert all(rp(np.complex64, m, "auto", 2) == "precise" for m in (9, 11, 13, 15))
+    assert rp(np.complex64, 16, "auto") == "precise"                 # n_src defaults to all channels
+    assert rp(np.complex64, 16, "fast", 2) == "fast" and rp(np.complex128, 4, "mixed", 2) == "mixed"
+
+
 def test_shard_bounds():
     from overiva_amd import shard_bounds
 

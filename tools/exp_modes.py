@@ -33,7 +33,10 @@ def run(X, K, model, n_iter, flags, splits=0):
 
 
 worst = {m: 0.0 for m, _ in MODES}
+ONLY = os.environ.get("OIVA_EXP_FIXTURES")          # e.g. "l,o,p,q": only these fixtures, and no long-frame-axis part
 for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "overiva_*_mix.npz"))):
+    if ONLY and os.path.basename(path)[8:-8] not in ONLY.split(","):
+        continue
     g = np.load(path)
     X, K = g["X"], int(g["K"])
     name = os.path.basename(path)[8:-4]
@@ -57,6 +60,8 @@ for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "..", "test
             print(f"{name:6s} {model:7s} n={n:2d} amp {amp:6.1f} floor {floor:.1e} | " + " | ".join(row), flush=True)
 print("worst (floors, where floor > 2e-7):", {k: round(v, 2) for k, v in worst.items()}, flush=True)
 
+if ONLY:
+    sys.exit(0)
 # long frame axis: the float32 chains of the covariance pass are 62 frames at 4 splits
 T, F, M, K = 4000, 256, 8, 2
 for seed in (3, 4):
