@@ -61,9 +61,10 @@ MODES = ("fast", "mixed", "precise")
 MODE_TEXT = {
     "fast": "fast (float32 products, lane chains and per-bin algebra; float64 sums across lanes and frame splits)",
     "mixed": "mixed (float32 products and lane chains of the covariance pass, float64 sums across lanes / splits, float64 per-bin "
-             "algebra with W_hat in complex128: what overiva() runs for complex64 input on <= 8 channels)",
+             "algebra with W_hat in complex128: what overiva() runs for complex64 input on <= 8 channels, and on 10/12/14/16 "
+             "channels with <= 4 sources)",
     "precise": "precise (float64 covariance accumulation on the fp64 matrix cores + float64 per-bin algebra: what overiva() runs "
-               "for complex128 input and for 9..16 channels)",
+               "for complex128 input and for the other 9..16-channel shapes)",
 }
 
 
@@ -679,10 +680,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=4, help="extra measurements of the same K steps for value_median (N = 1)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="headline",
                     help="headline: BASELINE.json configs[2] (the metric's workload); cfg5: configs[4], 16 mics / 16 sources; "
-                         "cfg2: configs[1]; shard8: one rank's shard of configs[3]; tiny: test-only")
+                         "cfg2: configs[1]; shard8: one rank's shard of configs[3]; m16k2: 16 mics / 2 sources; tiny: test-only")
     ap.add_argument("--precision", choices=list(MODES), default=None,
-                    help="arithmetic of the timed run (default: what overiva() runs on this input -- mixed up to 8 channels, "
-                         "precise for 9..16); the other modes are timed too")
+                    help="arithmetic of the timed run (default: what overiva() runs on this input -- mixed up to 8 channels and for "
+                         "10/12/14/16 channels with <= 4 sources, precise otherwise); the other modes are timed too")
     ap.add_argument("--cfg5-precision", choices=list(MODES), default="fast",
                     help="arithmetic of the configs[4] entry of the N = 1 line (overiva() runs it in precise; fast is the "
                          "float32 matrix-core form the roofline of that shape is about)")
@@ -703,7 +704,7 @@ def main():
     args = ap.parse_args()
     select_config(args.config)
     if args.precision is None:
-        args.precision = "mixed" if M <= 8 else "precise"
+        args.precision = "mixed" if M <= 8 or (M % 2 == 0 and K <= 4) else "precise"      # overiva_amd.overiva.resolve_precision
     world_env = int(os.environ.get("WORLD_SIZE", "0") or 0)
     if args.gpus > 1 and world_env == 0:
         # no launcher around us: be one.  Nothing above touched a GPU (no torch import, no HIP call).

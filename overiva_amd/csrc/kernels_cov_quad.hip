@@ -54,7 +54,7 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 // whole DMA queue (vmcnt(0)) in front of any LDS read it can see.  ad = {own, next, far, half}.
 template <int OFF, bool WAIT>
 __device__ __forceinline__ void quad_read(const unsigned (&ad)[4], float4 (&v)[7]) {
-    if constexpr (WAIT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if constexpr (WAIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kQuadStages - 1) * 2 * kQuadFrames) : "memory");
     asm volatile(
         "ds_read_b128 %0, %7 offset:%11\n\t"
         "ds_read_b128 %1, %7 offset:%12\n\t"
@@ -224,7 +224,6 @@ __global__ __launch_bounds__(kBlock, 2) void cov_quad_kernel(const float2* __res
 
     QuadAcc<KC> acc;
     acc.clear();
-
     // ---- DMA side: the LDS image of a frame is the run as it lies in memory ([bin][channel], bin stride M*8 bytes): lane l
     //      of instruction h moves 16-byte piece h * 64 + l; pieces past the run (fewer than 16 channels, fewer than 16 bins
     //      left) re-request its last piece and land in unused LDS.  (ds_read_b128 on this image is 2-way bank-conflicted
@@ -258,21 +257,30 @@ __global__ __launch_bounds__(kBlock, 2) void cov_quad_kernel(const float2* __res
     const int g = j & 1;
     const unsigned ad[4] = {lbase + 32u * j, lbase + 32u * ((j + 1) & 3), lbase + 32u * (g + 2), lbase + 32u * g + 16u * (j >> 1)};
 
-    auto consume = [&](int i, auto stage) {
-        constexpr int S = decltype(stage)::value;
-        // the weights of the wave's two frames: wave-uniform, scalar loads from the table (T, 16) whose columns past K are 0
-        v2f w[kQuadFrames];
+    // the weights of the wave's two frames of a step: wave-uniform scalar loads from the table (T, 16), whose columns past K
+    // are 0.  They are requested ONE STEP AHEAD (between the first frame's operand reads and its arithmetic): fetched at
+    // the head of their own step, every step began with a wait for a scalar load that misses the scalar cache (the table
+    // is walked with a stride of 8 rows) -- 27 % of the wave cycles of the arithmetic-only form of this kernel (PMC).
+    v2f wraw[kQuadFrames];
+    auto request_weights = [&](int i, v2f (&raw)[kQuadFrames]) {
 #pragma unroll
         for (int u = 0; u < kQuadFrames; ++u) {
-            const int t = t_begin + 4 * kQuadFrames * i + kQuadFrames * wave + u;
-            const bool live = t < t_end;
             if constexpr (UNIT) {
-                w[u] = v2f{live ? 1.f : 0.f, 0.f};
+                raw[u] = v2f{1.f, 0.f};
             } else {
+                const int t = t_begin + 4 * kQuadFrames * i + kQuadFrames * wave + u;
                 const float* wp = Wt + (size_t)min(t, T - 1) * kQuadWeightStride + k0;
-                const float w0 = wp[0], w1 = KC == 2 ? wp[1] : 0.f;
-                w[u] = v2f{live ? w0 : 0.f, live ? w1 : 0.f};
+                raw[u] = v2f{wp[0], KC == 2 ? wp[1] : 0.f};
             }
+        }
+    };
+    auto consume = [&](int i, auto stage) {
+        constexpr int S = decltype(stage)::value;
+        v2f w[kQuadFrames], wnext[kQuadFrames];
+#pragma unroll
+        for (int u = 0; u < kQuadFrames; ++u) {
+            const bool live = t_begin + 4 * kQuadFrames * i + kQuadFrames * wave + u < t_end;
+            w[u] = v2f{live ? wraw[u].x : 0.f, live ? wraw[u].y : 0.f};
         }
 #pragma unroll
         for (int u = 0; u < kQuadFrames; ++u) {
@@ -285,18 +293,27 @@ __global__ __launch_bounds__(kBlock, 2) void cov_quad_kernel(const float2* __res
             const v2f next[4] = {v2f{v[2].x, v[2].y}, v2f{v[2].z, v[2].w}, v2f{v[3].x, v[3].y}, v2f{v[3].z, v[3].w}};
             const v2f far[4] = {v2f{v[4].x, v[4].y}, v2f{v[4].z, v[4].w}, v2f{v[5].x, v[5].y}, v2f{v[5].z, v[5].w}};
             const v2f half[2] = {v2f{v[6].x, v[6].y}, v2f{v[6].z, v[6].w}};
+            if (u == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                request_weights(i + 1, wnext);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             acc.add(own, next, half, far, w[u]);
             __builtin_amdgcn_sched_barrier(0);      // keep the next frame's operand reads behind this frame's arithmetic (registers)
         }
+#pragma unroll
+        for (int u = 0; u < kQuadFrames; ++u) wraw[u] = wnext[u];
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
     using S3 = std::integral_constant<int, 3>;
+    static_assert(kQuadStages == 4, "the loop below is unrolled for a 4-stage ring");
 
     issue(0, 0);
     issue(1, 1);
     issue(2, 2);
+    request_weights(0, wraw);
     int i = 0;
     for (; i + 4 <= nsteps; i += 4) {       // stage indices are compile-time constants in the unrolled body
         issue(i + 3, 3); consume(i, S0{});

@@ -41,6 +41,15 @@ for c in "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
     i=$((i + 1))
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_cfg5/p$i" -o p -- $B --config cfg5 --precision fast $HEAD > /dev/null 2>&1
 done
+# 16 channels / 2 sources (the four-lanes-per-(bin, frame) covariance kernel), default arithmetic of that shape
+$B --config m16k2 --no-cpu > "$OUT/bench_m16k2.json" 2> "$OUT/bench_m16k2.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_m16k2" -o s -- $B --config m16k2 --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
+i=0
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" \
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS GRBM_GUI_ACTIVE"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_m16k2/p$i" -o p -- $B --config m16k2 $HEAD > /dev/null 2>&1
+done
 # the X-resident kernel: HBM traffic per launch of 50 iterations (X once + the exchange words), shard of the headline shape and configs[1]
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE"; do

@@ -54,13 +54,14 @@ def counters(sub):
 def main():
     os.makedirs(DST, exist_ok=True)
     for name, out in (("bench_n1.json", "bench_n1.json"), ("bench_cfg5.json", "bench_cfg5.json"),
-                      ("bench_sharded_1rank.json", "bench_sharded_1rank.json")):
+                      ("bench_sharded_1rank.json", "bench_sharded_1rank.json"), ("bench_m16k2.json", "bench_m16k2.json")):
         path = os.path.join(SRC, name)
         if os.path.exists(path):
             line = [l for l in open(path).read().splitlines() if l.startswith("{")][-1]
             json.dump(json.loads(line), open(os.path.join(DST, f"{TAG}_{out}"), "w"), indent=1)
     stats("stats_headline", f"{TAG}_kernel_stats.csv")
     stats("stats_cfg5", f"{TAG}_cfg5_kernel_stats.csv")
+    stats("stats_m16k2", f"{TAG}_m16k2_kernel_stats.csv")
     stats("stats_resident", f"{TAG}_resident_shard8_kernel_stats.csv")
     res = {}
     for sub, what in (("pmc_resident_shard8", "256 x 4000 x 8 / 2 (65.5 MB of X), 50 iterations per launch"),
@@ -114,6 +115,18 @@ def main():
                        "summed over the chip.  SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs) against GRBM_GUI_ACTIVE / 8 XCDs "
                        "is the fraction of the kernel the matrix pipes are busy.",
                "kernels": cfg5}, open(os.path.join(DST, f"{TAG}_cfg5_mfma_pmc.json"), "w"), indent=1)
+    m16 = counters("pmc_m16k2")
+    for k, cs in m16.items():
+        if "FETCH_SIZE" in cs:
+            cs["fetch_bytes_corrected"] = cs["FETCH_SIZE"] * 2048
+        if "WRITE_SIZE" in cs:
+            cs["write_bytes"] = cs["WRITE_SIZE"] * 1024
+    if m16:
+        json.dump({"note": "rocprofv3 --pmc (one pass per counter group) --kernel-trace, python3 bench.py --config m16k2 --steps 6 "
+                           "--warmup 2 --no-cpu --no-other-mode --no-configs --graph 0 (2048 x 4000 x 16 / 2, mixed mode, 8 frame "
+                           "splits; tools/collect_profiles.sh), MI355X; averages per launch, summed over the chip.  SQ *_CYCLES / "
+                           "ACTIVE / WAIT counters are in units of 4 shader cycles; GRBM_GUI_ACTIVE / 8 XCDs = shader cycles of the "
+                           "launch.", "kernels": m16}, open(os.path.join(DST, f"{TAG}_m16k2_pmc.json"), "w"), indent=1)
     for k, cs in cfg5.items():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and cs.get("GRBM_GUI_ACTIVE"):
             print(f"{k}: matrix pipes busy {cs['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (cs['GRBM_GUI_ACTIVE'] / 8):.2f}")
