@@ -63,7 +63,7 @@ MODE_TEXT = {
     "mixed": "mixed (float32 products and lane chains of the covariance pass, float64 sums across lanes / splits, float64 per-bin "
              "algebra with W_hat in complex128: what overiva() runs for complex64 input on <= 8 channels, and on 10/12/14/16 "
              "channels with <= 4 sources)",
-    "precise": "precise (float64 covariance accumulation on the fp64 matrix cores + float64 per-bin algebra: what overiva() runs "
+    "precise": "precise (covariance as float64 sums of exact float64 products + float64 per-bin algebra: what overiva() runs "
                "for complex128 input and for the other 9..16-channel shapes)",
 }
 
@@ -215,7 +215,8 @@ def _cov_roofline(shape, mode, cov_ms):
     if m <= 8:
         bytes_cov = cov_algorithmic_bytes(t, f, m, k)
         achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
-        kname = f"cov_gram_kernel<{min(k, 2)}>" if mode == "precise" else f"cov_dma_kernel<{m}, {min(k, 2)}>"
+        kname = (f"cov_pair64_kernel<{min(k, 2)}, false>" if m == 8 else f"cov_kernel<{m}, {min(k, 2)}, false, double>") if mode == "precise" \
+            else f"cov_dma_kernel<{m}, {min(k, 2)}>"
         return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, overiva.py:179)",
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms}

@@ -44,9 +44,10 @@ extern "C" {
  * complex64; these bits choose where float64 is used on top of it.
  *   0                      : float32 everywhere (fp32 matrix-core chains of 8 frames folded into float64).
  *   OIVA_PREC_UPDATE_F64   : the per-bin algebra (overiva.py:181-190) in float64, W_hat carried in complex128.
- *   OIVA_PREC_COV_F64      : the weighted covariance (overiva.py:179) accumulated in float64 on the fp64 matrix
- *                            cores -- the reference's own arithmetic there: its float64 r_inv promotes that
- *                            product to complex128 even for complex64 input (overiva.py:127-128).
+ *   OIVA_PREC_COV_F64      : the weighted covariance (overiva.py:179) as float64 sums of exact float64 products (up to 8
+ *                            channels: v_fma_f64 on the vector ALU; 9..16: fp64 matrix cores) -- the reference's own
+ *                            arithmetic there: its float64 r_inv promotes that product to complex128 even for
+ *                            complex64 input (overiva.py:127-128).
  *   OIVA_PREC_PRECISE      : both; what overiva() selects for complex128 input.
  *   OIVA_PREC_UPDATE_ROWS  : lane layout of the per-bin algebra (one lane per matrix row instead of per element). */
 #define OIVA_PREC_FAST 0

@@ -1,6 +1,6 @@
 // Weighted spatial covariance pass, vector-ALU form: 1..8 channels in float32 (the dominant kernel of the
-// iteration at the headline shape), 1, 2, 3, 5, 6, 7 channels in the float64 accumulation mode (4 and 8
-// channels then run on the fp64 matrix cores, kernels_cov_gram.hip; 9..16 channels: kernels_cov_mfma.hip).
+// iteration at the headline shape) and 1..7 channels in the float64 accumulation mode (8 channels in float64:
+// kernels_cov_pair64.hip; 9..16 channels: kernels_cov_quad.hip, kernels_cov_mfma.hip).
 //
 //   V_k[f] = sum_t rinv[t,k] * x_{t,f} x_{t,f}^H          reference overiva.py:179 (all k in one pass)
 //   Cx[f]  = sum_t x_{t,f} x_{t,f}^H                      reference overiva.py:87   (unit weights)
@@ -380,7 +380,7 @@ bool cov_supported(int M) { return M >= 1 && M <= OIVA_MAX_CHANNELS; }
 
 // sources handled per pass over X
 int cov_sources_per_pass(int M, int K, bool f64) {
-    if (f64 && cov_gram_supported(M)) return cov_gram_sources_per_pass(K);
+    if (f64 && cov_pair64_supported(M)) return cov_pair64_sources_per_pass(K);
     const int regs = M * M * (f64 ? 2 : 1);   // as many as fit the accumulator budget (KC * M^2 <= 144 registers)
     int kc = 1;
     if (K >= 2 && regs * 2 <= 144) kc = 2;
@@ -392,7 +392,7 @@ hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt,
                       void* Vpart, bool f64, int T, int F, int M, int K, const CovGeom& g) {
     if (M > 8 && g.quad && !f64) return launch_cov_quad(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
     if (M > 8) return launch_cov_mfma(s, X, R, Wt, wscale, model, raw, Vpart, f64, T, F, M, K, g.nsplit, g.tc);
-    if (f64 && cov_gram_supported(M)) return launch_cov_gram(s, X, R, wscale, model, raw, Vpart, T, F, M, K, g);
+    if (f64 && cov_pair64_supported(M)) return launch_cov_pair64(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
     const int kc = R == nullptr ? 1 : g.kc;
     if (f64)
         return dispatch_cov<double>(M, kc, R == nullptr, [&](CovKernel<double> kern, int KC) {
@@ -408,7 +408,10 @@ hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt,
 
 // workgroups of this instantiation that one CU holds at once (registers / LDS limited)
 hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n) {
-    if (f64 && cov_gram_supported(M)) return cov_gram_blocks_per_cu(kc, n);
+    if (f64 && cov_pair64_supported(M)) {
+        *n = 2;
+        return hipSuccess;
+    }
     if (f64)
         return dispatch_cov<double>(M, kc, false, [&](CovKernel<double> kern, int) {
             return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, kern, kBlock, 0);

@@ -86,14 +86,6 @@ constexpr int kPowMaxFrames = 512;
 //   f64: accumulate in float64 (the reference's arithmetic: its float64 r_inv promotes overiva.py:179 to complex128)
 hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                       void* Vpart, bool f64, int T, int F, int M, int K, const CovGeom& g);
-// float64 real-Gram kernel on the fp64 matrix cores for 4 and 8 channels (kernels_cov_gram.hip); tc multiple of 4,
-// Vpart float64
-bool cov_gram_supported(int M);
-int cov_gram_sources_per_pass(int K);
-int cov_gram_max_frames();   // frames per workgroup the kernel can take
-hipError_t launch_cov_gram(hipStream_t s, const float2* X, const float* R, float* wscale, int model, int raw, void* Vpart,
-                           int T, int F, int M, int K, const CovGeom& g);
-hipError_t cov_gram_blocks_per_cu(int kc, int* n);
 // planar matrix-core kernel for 9..16 channels (grid = F bins x nsplit, tc frames per split, tc multiple of 4)
 //   Wt (T,16): scratch for the final weights (written by a small pre-pass)
 hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
@@ -107,6 +99,14 @@ hipError_t launch_cov_quad(hipStream_t s, const float2* X, const float* R, float
                            double* Vpart, int T, int F, int M, int K, const CovGeom& g);
 // pre-pass of the 9..16-channel kernels: Wt (T, Kp) = 1 / max(r / gamma, eps), columns >= K zero; writes wscale (K)
 hipError_t launch_cov_weights(hipStream_t s, const float* R, float* Wt, float* wscale, int model, int raw, int T, int K, int Kp);
+// float64 vector-ALU kernel for 8 channels (kernels_cov_pair64.hip): the Hermitian half split over two lanes per (bin, frame),
+// 32 bins per workgroup (grid.x = ceil(F / 32)), tc multiple of 8, Vpart float64; Wt: the (T, 16) float scratch, used as
+// (T, 8) doubles; R == nullptr: unit weights (K = 1)
+bool cov_pair64_supported(int M);
+int cov_pair64_sources_per_pass(int K);
+int cov_pair64_bins_per_block();
+hipError_t launch_cov_pair64(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
+                             double* Vpart, int T, int F, int M, int K, const CovGeom& g);
 int cov_sources_per_pass(int M, int K, bool f64);
 hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n);
 bool cov_supported(int M);

@@ -137,9 +137,9 @@ int pick_splits(int capacity, int blocks_per_split, int T, int min_frames) {
 
 void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     CovGeom g;
-    const bool gram = p->cov_f64() && cov_gram_supported(p->M);
-    // workgroups along the bin axis: 16 tiles of 16 floats (matrix-core kernel, 4 / 8 channels) or 16 bins
-    g.nbg = gram ? ceil_div(ceil_div(p->F * p->M * 2, 16), 16) : ceil_div(p->F, kBinsPerWave);
+    // float64, 8 channels: two lanes per (bin, frame), 32 bins per workgroup (kernels_cov_pair64.hip); else 16 bins
+    const bool pair = p->cov_f64() && cov_pair64_supported(p->M);
+    g.nbg = ceil_div(p->F, pair ? cov_pair64_bins_per_block() : kBinsPerWave);
     g.kc = cov_sources_per_pass(p->M, p->K, p->cov_f64());
     const int nz = ceil_div(p->K, g.kc);
     int nsplit = nsplit_req;
@@ -180,7 +180,7 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         p->cov = g;
         return;
     }
-    const int quantum = gram ? 4 : 16;      // frames per step of a workgroup
+    const int quantum = pair ? 8 : 16;      // frames per step of a workgroup
     if (nsplit <= 0) {
         int bpc = 2;
         if (cov_blocks_per_cu(p->M, g.kc, p->cov_f64(), &bpc) != hipSuccess || bpc < 1) bpc = 2;
@@ -196,7 +196,6 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         const int cap = (g.nbg * nz * 32 >= p->n_cu) ? 32 : 64;
         nsplit = std::min(nsplit, cap);
     }
-    if (gram) nsplit = std::max(nsplit, ceil_div(p->T, cov_gram_max_frames() - 4));   // the kernel's weight table
     g.tc = round_up(ceil_div(p->T, nsplit), quantum);
     g.nsplit = ceil_div(p->T, g.tc);
     p->cov = g;

@@ -1,13 +1,15 @@
 """Drop-in ``overiva()`` -- same name, argument order, defaults and return values as reference
 ``overiva.py:28-38``; the body runs on one MI355X (or bin-sharded over several, see ``sharded.py``).
 
-Arithmetic (``set_precision``): device data (X, Y) is complex64 whatever the input dtype.  In ``"precise"``
-mode the weighted covariance is accumulated in float64 on the fp64 matrix cores and the per-bin algebra runs in
-float64 with W_hat carried in complex128 -- the reference's complex128 arithmetic (``overiva.py:89,126-131``)
-applied to complex64-rounded data; it is the default for every input dtype because only it reproduces the
-reference to within the reference's own complex64 noise on ill-conditioned (mixture-like) input.  In ``"fast"``
-mode everything is float32: 1.4x faster at the headline shape, 1e-5 on well-conditioned input, a few times the
-reference's complex64 noise otherwise (tests/test_gpu_parity.py::test_fast_mode_accuracy).
+Arithmetic (``set_precision``): device data (X, Y) is complex64 whatever the input dtype.  ``"auto"`` (default) follows
+the reference, which computes in the dtype of X (``overiva.py:89,126-131``): complex128 input runs ``"precise"`` -- the
+weighted covariance as float64 sums of exact float64 products and the per-bin algebra in float64 with W_hat carried in
+complex128, i.e. the reference's complex128 arithmetic applied to complex64-rounded data; complex64 input runs ``"mixed"``
+-- float32 products and short float32 lane chains in the covariance pass, every longer sum and the per-bin algebra in
+float64: closer to the reference's complex128 result than the reference's own complex64 arithmetic is -- wherever the
+covariance kernel of the shape provides that (``resolve_precision``).  ``"fast"`` is float32 in the per-bin algebra too:
+1e-5 on well-conditioned input, a few times the reference's complex64 noise otherwise
+(tests/test_gpu_parity.py::test_fast_mode_accuracy).
 
 Documented deviations from the reference:
 * X is held as complex64 on the device even for complex128 input (a 6e-8 relative input perturbation); the

@@ -224,7 +224,7 @@ class Plan:
     def set_precision(self, mode="fast", row_layout=False):
         """``"fast"`` (float32 products, lane chains and per-bin algebra), ``"mixed"`` (float32 products and lane
         chains of the covariance pass, float64 sums across lanes / splits and float64 per-bin algebra, W_hat carried in
-        complex128), ``"precise"`` (float64 covariance accumulation on the fp64 matrix cores + float64 algebra: the
+        complex128), ``"precise"`` (float64 sums of exact float64 products in the covariance pass + float64 algebra: the
         reference's complex128 arithmetic on complex64 data), or an int of ``_lib.PREC_*`` bits."""
         flags = _lib.PREC_BY_NAME[mode] if isinstance(mode, str) else int(mode)
         if row_layout:

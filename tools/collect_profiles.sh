@@ -28,7 +28,7 @@ for c in "FETCH_SIZE" "WRITE_SIZE" \
     i=$((i + 1))
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_headline/p$i" -o p -- $B $HEAD > /dev/null 2>&1
 done
-# HBM traffic of the precise mode (float64 covariance on the fp64 matrix cores, float64 per-bin algebra)
+# HBM traffic of the precise mode (float64 covariance on the vector ALU, float64 per-bin algebra)
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i + 1))

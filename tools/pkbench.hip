@@ -11,6 +11,8 @@ using v2f = __attribute__((ext_vector_type(2))) float;
 // MODE 1: v_pk_fma_f32 plain, 16 independent accumulator pairs, three distinct VGPR-pair sources
 // MODE 2: v_pk_fma_f32 with the op_sel broadcast forms of cov_arith.h (w0 / w1 / hi_swap) + v_pk_mul neg_hi
 // MODE 3: as 2, 64 accumulator pairs (the register footprint of the real kernels)
+// MODE 4: v_fma_f64, 16 independent accumulators;  MODE 5: v_cvt_f64_f32 + v_mul_f64 + v_fma_f64 in the mix of the float64
+//         Hermitian-half kernel (1 : 3 : 9)
 template <int MODE>
 __global__ __launch_bounds__(256) void bench(float* out, unsigned long long* clk, int iters, float seed) {
     constexpr int NA = MODE == 3 ? 64 : 16;
@@ -26,6 +28,30 @@ __global__ __launch_bounds__(256) void bench(float* out, unsigned long long* clk
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < NA; ++i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i].x) : "v"(x[i & 7].x), "v"(x[(i + r) & 7].y));
+        } else if constexpr (MODE == 4) {
+            double* d = reinterpret_cast<double*>(acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+                    asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(d[i]) : "v"(*reinterpret_cast<double*>(&x[i & 7])), "v"(*reinterpret_cast<double*>(&x[(i + r + 1) & 7])));
+        } else if constexpr (MODE == 5) {
+            double* d = reinterpret_cast<double*>(acc);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double c0, c1, p0, p1, p2;
+                asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(c0) : "v"(x[g].x));
+                asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(c1) : "v"(x[g + 4].y));
+                asm volatile("v_mul_f64 %0, %1, %2" : "=v"(p0) : "v"(c0), "v"(c1));
+                asm volatile("v_mul_f64 %0, %1, %1" : "=v"(p1) : "v"(c0));
+                asm volatile("v_mul_f64 %0, %1, %1" : "=v"(p2) : "v"(c1));
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(d[(g * 3 + e) & 15]) : "v"(p0), "v"(c0));
+                    asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(d[(g * 3 + e + 5) & 15]) : "v"(p1), "v"(c1));
+                    asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(d[(g * 3 + e + 10) & 15]) : "v"(p2), "v"(c0));
+                }
+            }
         } else if constexpr (MODE == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -90,6 +116,8 @@ int main() {
         run<1>("v_pk_fma_f32 plain x64", bpc, 64);
         run<2>("pk_mul + 3 pk_fma (op_sel forms) x64", bpc, 64);
         run<3>("same, 64 accumulator pairs x256", bpc, 256);
+        run<4>("v_fma_f64 x64", bpc, 64);
+        run<5>("cvt_f64_f32 : mul_f64 : fma_f64 = 8 : 12 : 36", bpc, 56);
     }
     return 0;
 }
