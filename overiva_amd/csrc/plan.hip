@@ -227,7 +227,12 @@ void choose_pow_geom(oiva_plan* p, int nsplit_req) {
         // least 64 frames (16 steps per wave) per workgroup: each one loads its W first (256-bin shard: 62 splits
         // 13.5 us, 167 splits 15.9 us).
         // (counted per source pass: with 8 sources in two passes, 12 splits 112 us, 6 splits 127-137 us)
-        nsplit = pick_splits(std::max(p->n_cu / 2, p->n_cu * 12 / std::max(p->M, 1)), g.nb, p->T, 64);
+        // ONE source per pass halves the arithmetic per byte and a wave runs through its two steps in flight before the next
+        // ones arrive: twice the workgroups (8 channels / 1 source: 12 splits 111 us, 24 splits 92.5; with 2-4 sources 24
+        // splits measure the same as 12)
+        // (not beyond 8 channels: 16 channels / 1 source 6 splits 226 us, 12 splits -- 1.5 rounds of workgroups -- 276)
+        const int per_cu_x12 = (g.kp == 1 && p->M <= 8) ? 24 : 12;
+        nsplit = pick_splits(std::max(p->n_cu / 2, p->n_cu * per_cu_x12 / std::max(p->M, 1)), g.nb, p->T, 64);
     }
     int tcp = round_up(ceil_div(p->T, nsplit), 4);
     tcp = std::min(std::max(tcp, 4), kPowMaxFrames);
