@@ -215,8 +215,10 @@ def _cov_roofline(shape, mode, cov_ms):
     if m <= 8:
         bytes_cov = cov_algorithmic_bytes(t, f, m, k)
         achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
-        kname = (f"cov_pair64_kernel<{min(k, 2)}, false>" if m == 8 else f"cov_kernel<{m}, {min(k, 2)}, false, double>") if mode == "precise" \
-            else f"cov_dma_kernel<{m}, {min(k, 2)}>"
+        if mode == "precise":
+            kname = f"cov_pair64_kernel<{min(k, 2)}, false>" if m == 8 else f"cov_kernel<{m}, {min(k, 2)}, false, double>"
+        else:
+            kname = "cov_pair32_kernel<false>" if m == 8 and k >= 3 else f"cov_dma_kernel<{m}, {min(k, 2)}>"
         return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, overiva.py:179)",
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms}

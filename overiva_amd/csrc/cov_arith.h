@@ -89,6 +89,43 @@ __device__ __forceinline__ v2f pk_fma_w1(v2f w, v2f p, v2f c) {         // c + w
     return r;
 }
 
+// The same packed forms as VOLATILE asm with the accumulator tied to the result: the compiler keeps volatile asm in source
+// order (it reorders plain asm statements freely, which in the kernels that carry 128 accumulators next to 28 operand
+// registers stretched the live ranges of the products past what 256 registers hold).
+__device__ __forceinline__ v2f qk_mul_lo_negim(v2f a, v2f b) {          // (a.x * b.x, -(a.x * b.y))
+    v2f r;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void qk_fma_hi_swap(v2f a, v2f b, v2f& c) {   // c += (a.y * b.y, a.y * b.x)
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void qk_fma_w0(v2f w, v2f p, v2f& c) {        // c += w.x * p
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(c) : "s"(w), "v"(p));
+}
+__device__ __forceinline__ void qk_fma_w1(v2f w, v2f p, v2f& c) {        // c += w.y * p
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(c) : "s"(w), "v"(p));
+}
+
+// 8 x 8 Hermitian half split over the two lanes of a pair (kernels_cov_pair32.hip, kernels_cov_pair64.hip): channel groups
+// A = 0..3, B = 4..7; lane j holds the diagonal block of group j (sums 0..3: the real diagonals; then (re, im) of its 6
+// entries r < c) and rows 2j, 2j+1 of A x B (8 entries) = 32 real sums.  Sum a of lane j -> position in the packed layout.
+__device__ __forceinline__ int pair_position(int j, int a) {
+    if (a < 4) return 4 * j + a;
+    const int p = (a - 4) >> 1, im = (a - 4) & 1;
+    int c, d;
+    if (p < 6) {
+        const int r = p < 3 ? 0 : (p < 5 ? 1 : 2);
+        const int cc = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
+        c = 4 * j + r;
+        d = 4 * j + cc;
+    } else {
+        c = 2 * j + ((p - 6) >> 2);
+        d = 4 + ((p - 6) & 3);
+    }
+    return herm_pair_index(8, c, d) + im;
+}
+
 // accumulators of TWO sources in that layout: off-diagonal entries as (re, im) pairs, diagonals as scalars
 template <int M>
 struct PkAcc2 {

@@ -381,6 +381,7 @@ bool cov_supported(int M) { return M >= 1 && M <= OIVA_MAX_CHANNELS; }
 // sources handled per pass over X
 int cov_sources_per_pass(int M, int K, bool f64) {
     if (f64 && cov_pair64_supported(M)) return cov_pair64_sources_per_pass(K);
+    if (!f64 && cov_pair32_supported(M, K)) return cov_pair32_sources_per_pass();
     const int regs = M * M * (f64 ? 2 : 1);   // as many as fit the accumulator budget (KC * M^2 <= 144 registers)
     int kc = 1;
     if (K >= 2 && regs * 2 <= 144) kc = 2;
@@ -392,6 +393,7 @@ hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt,
                       void* Vpart, bool f64, int T, int F, int M, int K, const CovGeom& g) {
     if (M > 8 && g.quad && !f64) return launch_cov_quad(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
     if (M > 8) return launch_cov_mfma(s, X, R, Wt, wscale, model, raw, Vpart, f64, T, F, M, K, g.nsplit, g.tc);
+    if (!f64 && g.pair32) return launch_cov_pair32(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
     if (f64 && cov_pair64_supported(M)) return launch_cov_pair64(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
     const int kc = R == nullptr ? 1 : g.kc;
     if (f64)
@@ -408,7 +410,7 @@ hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt,
 
 // workgroups of this instantiation that one CU holds at once (registers / LDS limited)
 hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n) {
-    if (f64 && cov_pair64_supported(M)) {
+    if ((f64 && cov_pair64_supported(M)) || (!f64 && M == 8 && kc == 4)) {
         *n = 2;
         return hipSuccess;
     }

@@ -27,6 +27,7 @@
 #include <cstdint>
 
 #include "oiva_device.h"
+#include "cov_arith.h"
 
 namespace oiva {
 namespace {
@@ -60,23 +61,6 @@ __device__ __forceinline__ void pair_read(const unsigned (&ad)[3], float4 (&v)[5
         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
         : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "n"(OFF), "n"(OFF + 16)
         : "memory");
-}
-
-// sum a (0..31) of lane j -> position in the packed Hermitian layout of an 8 x 8 matrix (herm_pair_index)
-__device__ __forceinline__ int pair_position(int j, int a) {
-    if (a < 4) return 4 * j + a;
-    const int p = (a - 4) >> 1, im = (a - 4) & 1;
-    int c, d;
-    if (p < 6) {
-        const int r = p < 3 ? 0 : (p < 5 ? 1 : 2);
-        const int cc = p < 3 ? p + 1 : (p < 5 ? p - 1 : 3);
-        c = 4 * j + r;
-        d = 4 * j + cc;
-    } else {
-        c = 2 * j + ((p - 6) >> 2);
-        d = 4 + ((p - 6) & 3);
-    }
-    return herm_pair_index(8, c, d) + im;
 }
 
 // acc[k][*] += w[k] * (entries of this lane):  x_c conj(x_d) = (xr_c xr_d + xi_c xi_d,  xi_c xr_d - xr_c xi_d)

@@ -69,23 +69,6 @@ __device__ __forceinline__ void quad_read(const unsigned (&ad)[4], float4 (&v)[7
         : "memory");
 }
 
-// the packed products of cov_arith.h as VOLATILE asm: the compiler then keeps them in source order (it reorders plain
-// asm statements freely, which here stretched the live ranges of the products past what 256 registers hold)
-__device__ __forceinline__ v2f qk_mul_lo_negim(v2f a, v2f b) {          // (a.x * b.x, -(a.x * b.y))
-    v2f r;
-    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ void qk_fma_hi_swap(v2f a, v2f b, v2f& c) {   // c += (a.y * b.y, a.y * b.x)
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(c) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void qk_fma_w0(v2f w, v2f p, v2f& c) {        // c += w.x * p
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(c) : "s"(w), "v"(p));
-}
-__device__ __forceinline__ void qk_fma_w1(v2f w, v2f p, v2f& c) {        // c += w.y * p
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(c) : "s"(w), "v"(p));
-}
-
 // entry p (0..29) of a lane = a[p] conj(b[p]):  p < 6 own x own (rows < columns), p < 22 own x next, else half x far
 struct QuadOperands {
     v2f a[kQuadPairs], b[kQuadPairs];

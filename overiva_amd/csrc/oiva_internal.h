@@ -67,6 +67,7 @@ struct CovGeom {
     int tc;       // frames per split (multiple of 16)
     int kc;       // sources per pass (template KC)
     int nbg;      // bin groups of 16 (grid.x)
+    int pair32 = 0; // 8 channels, >= 3 sources, float32: kernels_cov_pair32.hip (32 bins per workgroup, four sources per pass)
     int quad = 0; // 10/12/14/16 channels, few sources, float32: the vector-ALU kernel of kernels_cov_quad.hip (float64 partials)
 };
 struct PowGeom {
@@ -106,6 +107,14 @@ bool cov_pair64_supported(int M);
 int cov_pair64_sources_per_pass(int K);
 int cov_pair64_bins_per_block();
 hipError_t launch_cov_pair64(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
+                             double* Vpart, int T, int F, int M, int K, const CovGeom& g);
+// float32 kernel for 8 channels and three or more sources, FOUR per pass over X (kernels_cov_pair32.hip): the Hermitian half
+// over two lanes per (bin, frame), 32 bins per workgroup, tc multiple of 8, Vpart float64; Wt: (T, 16) scratch as for
+// launch_cov_mfma; R == nullptr: unit weights (K = 1) on the same geometry
+bool cov_pair32_supported(int M, int K);
+int cov_pair32_sources_per_pass();
+int cov_pair32_bins_per_block();
+hipError_t launch_cov_pair32(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                              double* Vpart, int T, int F, int M, int K, const CovGeom& g);
 int cov_sources_per_pass(int M, int K, bool f64);
 hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n);

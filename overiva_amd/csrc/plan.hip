@@ -138,7 +138,9 @@ int pick_splits(int capacity, int blocks_per_split, int T, int min_frames) {
 void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     CovGeom g;
     // float64, 8 channels: two lanes per (bin, frame), 32 bins per workgroup (kernels_cov_pair64.hip); else 16 bins
-    const bool pair = p->cov_f64() && cov_pair64_supported(p->M);
+    // (same geometry, float32: 8 channels with three or more sources, four per pass -- kernels_cov_pair32.hip)
+    g.pair32 = !p->cov_f64() && cov_pair32_supported(p->M, p->K);
+    const bool pair = g.pair32 || (p->cov_f64() && cov_pair64_supported(p->M));
     g.nbg = ceil_div(p->F, pair ? cov_pair64_bins_per_block() : kBinsPerWave);
     g.kc = cov_sources_per_pass(p->M, p->K, p->cov_f64());
     const int nz = ceil_div(p->K, g.kc);
@@ -195,6 +197,9 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         // streaming pass dominates and up to 64 splits are allowed
         const int cap = (g.nbg * nz * 32 >= p->n_cu) ? 32 : 64;
         nsplit = std::min(nsplit, cap);
+        // four frame phases per workgroup instead of 16: float32 chains four times as long at equal splits; with the
+        // float64 per-bin algebra behind it the pass takes at least 8 splits (see the 10..16-channel kernel above)
+        if (g.pair32 && p->upd_f64()) nsplit = std::max(nsplit, std::min(8, std::max(1, p->T / 8)));
     }
     g.tc = round_up(ceil_div(p->T, nsplit), quantum);
     g.nsplit = ceil_div(p->T, g.tc);
@@ -1052,8 +1057,9 @@ int oiva_plan_set_precision(oiva_plan* p, int flags) {
         std::vector<double2> wh;
         if ((rc = download_what(p, wh)) || (rc = upload_what(p, wh))) return rc;
     }
-    // (more than 8 channels: which float32 kernel takes the pass also depends on the arithmetic of the per-bin algebra)
-    const bool cov_changed = ((flags ^ p->prec) & (OIVA_PREC_COV_F64 | (p->M > 8 ? OIVA_PREC_UPDATE_F64 : 0))) != 0;
+    // (more than 8 channels: which float32 kernel takes the pass also depends on the arithmetic of the per-bin algebra;
+    // 8 channels with three or more sources: the number of frame splits does)
+    const bool cov_changed = ((flags ^ p->prec) & (OIVA_PREC_COV_F64 | ((p->M > 8 || p->cov.pair32) ? OIVA_PREC_UPDATE_F64 : 0))) != 0;
     p->prec = flags;
     if (cov_changed) {
         choose_cov_geom(p, 0);            // sources per pass and residency depend on the accumulator type
