@@ -61,10 +61,9 @@ MODES = ("fast", "mixed", "precise")
 MODE_TEXT = {
     "fast": "fast (float32 products, lane chains and per-bin algebra; float64 sums across lanes and frame splits)",
     "mixed": "mixed (float32 products and lane chains of the covariance pass, float64 sums across lanes / splits, float64 per-bin "
-             "algebra with W_hat in complex128: what overiva() runs for complex64 input on <= 8 channels, and on 10/12/14/16 "
-             "channels with <= 4 sources)",
+             "algebra with W_hat in complex128: what overiva() runs for complex64 input on <= 8 and on 10/12/14/16 channels)",
     "precise": "precise (covariance as float64 sums of exact float64 products + float64 per-bin algebra: what overiva() runs "
-               "for complex128 input and for the other 9..16-channel shapes)",
+               "for complex128 input and for 9/11/13/15 channels)",
 }
 
 
@@ -231,6 +230,21 @@ def _cov_roofline(shape, mode, cov_ms):
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
                        "note": "co-limited by the vector ALU: 512 real FMAs per (bin, frame, source pair) at 16 channels against 128 at 8"}
+    if m % 2 == 0 and mode != "precise" and k > 4:
+        # the Hermitian half on the vector ALU, 32 lanes per (bin, frame), every source in one pass: bound by the packed-fp32
+        # issue rate (2 + k instructions per complex entry slot, 160 slots per (bin, frame)), not by memory
+        bytes_cov = cov_algorithmic_bytes(t, f, m, k)
+        np_ = 4 if k <= 8 else (6 if k <= 12 else 8)
+        instr = 32.0 * (10 + 10 * np_) * t * f / 64            # packed wave-instructions per launch
+        floor_ms = instr / 1024 * 2.0e-6                       # 1024 SIMDs, 2.0 ns per packed instruction and SIMD (tools/pkbench.hip)
+        kname = f"cov_half16_kernel<{np_}, false>"
+        return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, overiva.py:179)",
+                       "achieved": bytes_cov / (cov_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": bytes_cov / (cov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_cov,
+                       "avg_launch_ms": cov_ms,
+                       "vector_alu": {"packed_wave_instructions_per_launch": instr, "issue_floor_ms": floor_ms, "frac_of_issue_floor": floor_ms / cov_ms},
+                       "note": "NOT memory-bound: the vector ALU's packed-fp32 issue rate bounds it (vector_alu); the fp32 matrix cores "
+                               "have the same peak and the planar form needs 2.8x the multiply-adds (it measured 1.69 ms at 16 x 16)"}
     naive = 8.0 * k * m * m * t * f            # complex MACs counted as 8 real flops
     issued = 6.0 * k * m * m * t * f           # what the planar form issues: 3 MFMAs of 16x16x4 per 4 frames and source
     kname = "cov_mfma16_kernel<double, 16>" if mode == "precise" else "cov_mfma16_kernel<float, 16>"
@@ -686,10 +700,9 @@ def main():
                          "cfg2: configs[1]; shard8: one rank's shard of configs[3]; m16k2: 16 mics / 2 sources; tiny: test-only")
     ap.add_argument("--precision", choices=list(MODES), default=None,
                     help="arithmetic of the timed run (default: what overiva() runs on this input -- mixed up to 8 channels and for "
-                         "10/12/14/16 channels with <= 4 sources, precise otherwise); the other modes are timed too")
-    ap.add_argument("--cfg5-precision", choices=list(MODES), default="fast",
-                    help="arithmetic of the configs[4] entry of the N = 1 line (overiva() runs it in precise; fast is the "
-                         "float32 matrix-core form the roofline of that shape is about)")
+                         "10/12/14/16 channels, precise otherwise); the other modes are timed too")
+    ap.add_argument("--cfg5-precision", choices=list(MODES), default="mixed",
+                    help="arithmetic of the configs[4] entry of the N = 1 line (default: what overiva() runs on it)")
     ap.add_argument("--no-other-mode", action="store_true", help="do not also time the other arithmetic modes")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (exercises RCCL + graph capture on 1 GPU)")
@@ -707,7 +720,7 @@ def main():
     args = ap.parse_args()
     select_config(args.config)
     if args.precision is None:
-        args.precision = "mixed" if M <= 8 or (M % 2 == 0 and K <= 4) else "precise"      # overiva_amd.overiva.resolve_precision
+        args.precision = "mixed" if M <= 8 or M % 2 == 0 else "precise"      # overiva_amd.overiva.resolve_precision
     world_env = int(os.environ.get("WORLD_SIZE", "0") or 0)
     if args.gpus > 1 and world_env == 0:
         # no launcher around us: be one.  Nothing above touched a GPU (no torch import, no HIP call).

@@ -67,6 +67,7 @@ struct CovGeom {
     int tc;       // frames per split (multiple of 16)
     int kc;       // sources per pass (template KC)
     int nbg;      // bin groups of 16 (grid.x)
+    int half16 = 0; // 10/12/14/16 channels, 5..16 sources, float32: kernels_cov_half16.hip (2 bins per workgroup, all sources per pass)
     int pair32 = 0; // 8 channels, >= 3 sources, float32: kernels_cov_pair32.hip (32 bins per workgroup, four sources per pass)
     int quad = 0; // 10/12/14/16 channels, few sources, float32: the vector-ALU kernel of kernels_cov_quad.hip (float64 partials)
 };
@@ -115,6 +116,13 @@ bool cov_pair32_supported(int M, int K);
 int cov_pair32_sources_per_pass();
 int cov_pair32_bins_per_block();
 hipError_t launch_cov_pair32(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
+                             double* Vpart, int T, int F, int M, int K, const CovGeom& g);
+// float32 vector-ALU kernel for 10, 12, 14, 16 channels and up to 16 sources in ONE pass (kernels_cov_half16.hip): the
+// Hermitian half over 32 lanes per (bin, frame), 2 bins per workgroup (grid.x = ceil(F / 2)), tc multiple of 16, Vpart
+// float64; Wt: (T + 1, 16) scratch (row T is zeroed by the launcher); R == nullptr: unit weights (K = 1)
+bool cov_half16_supported(int M, int K);
+int cov_half16_sources_per_pass(int K);
+hipError_t launch_cov_half16(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                              double* Vpart, int T, int F, int M, int K, const CovGeom& g);
 int cov_sources_per_pass(int M, int K, bool f64);
 hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n);

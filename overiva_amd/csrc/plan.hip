@@ -89,7 +89,7 @@ struct oiva_plan {
     // element type of the covariance partials: the vector-ALU kernels (<= 8 channels) always sum their float32 lane
     // chains across lanes in float64 and store float64 partials; the 9..16-channel matrix-core kernel stores its
     // accumulator type
-    bool vpart_f64() const { return cov_f64() || M <= 8 || cov.quad; }
+    bool vpart_f64() const { return cov_f64() || M <= 8 || cov.quad || cov.half16; }
     int use_graph = 0;
     // OGIVE (ive.py): per-bin state, allocated by oiva_plan_ogive_begin
     OgiveState og{};
@@ -165,6 +165,21 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
             if (p->upd_f64()) nsplit = std::max(nsplit, std::min(8, std::max(1, p->T / 8)));
         }
         g.tc = round_up(ceil_div(p->T, nsplit), 8);
+        g.nsplit = ceil_div(p->T, g.tc);
+        p->cov = g;
+        return;
+    }
+    // many sources (5..16): the Hermitian half over 32 lanes per (bin, frame), every source in one pass; a wave's float32
+    // chain is T / (4 nsplit) frames: <= 256 in `fast`, <= 128 with the float64 per-bin algebra behind it
+    if (p->M > 8 && !p->cov_f64() && p->cov_quad_on && p->K > 4 && cov_half16_supported(p->M, p->K)) {
+        g.half16 = 1;
+        g.nbg = ceil_div(p->F, 2);
+        g.kc = cov_half16_sources_per_pass(p->K);
+        if (nsplit <= 0) {
+            nsplit = ceil_div(p->T, p->upd_f64() ? 512 : 1024);
+            while (g.nbg * nsplit < 2 * p->n_cu && ceil_div(p->T, nsplit + 1) >= 64) ++nsplit;
+        }
+        g.tc = round_up(ceil_div(p->T, nsplit), 16);
         g.nsplit = ceil_div(p->T, g.tc);
         p->cov = g;
         return;
@@ -573,7 +588,7 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     alloc((void**)&p->Cx, nFMM * sizeof(double));
     alloc((void**)&p->Ppart, (size_t)p->pw.nb * nTK * sizeof(float));
     p->ppart_alloc = p->pw.nb;
-    alloc((void**)&p->Plocal, std::max(nTK, (size_t)T * 16) * sizeof(float));   // also the (T, 16) weights scratch
+    alloc((void**)&p->Plocal, std::max(nTK, ((size_t)T + 1) * 16) * sizeof(float));   // also the (T + 1, 16) weights scratch
     alloc((void**)&p->R, r_buffer_bytes(T, K));   // activations, zeroed pad rows, per-block sums (rsum_offset_floats)
     if (e == hipSuccess) e = hipMemset(p->R, 0, r_buffer_bytes(T, K));
     alloc((void**)&p->wscale, (size_t)K * sizeof(float));
@@ -1021,7 +1036,7 @@ int oiva_plan_set_cov_quad(oiva_plan* p, int enable, int* active) {
     if (rc) return rc;
     p->cov_quad_on = enable != 0;
     choose_cov_geom(p, 0);
-    if (active) *active = p->cov.quad;
+    if (active) *active = p->cov.quad || p->cov.half16;
     return ensure_vpart(p);
 }
 

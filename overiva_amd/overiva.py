@@ -43,16 +43,15 @@ def set_precision(mode):
 def resolve_precision(dtype, n_chan, mode=None, n_src=None):
     """``"auto"`` follows the reference, which computes in the dtype of X (overiva.py:89,126,131): complex128 input ->
     ``"precise"``; complex64 input -> ``"mixed"`` wherever the covariance pass hands float64 sums of short float32
-    chains to the float64 per-bin algebra: up to 8 channels, and 10 / 12 / 14 / 16 channels with at most 4 sources
-    (csrc/kernels_cov_quad.hip); the other 9..16-channel shapes run the matrix-core pass, whose float32 form keeps
-    float32 partial sums -> ``"precise"``"""
+    chains to the float64 per-bin algebra: up to 8 channels and 10 / 12 / 14 / 16 channels (csrc/kernels_cov_quad.hip,
+    csrc/kernels_cov_half16.hip); 9, 11, 13 and 15 channels run the matrix-core pass, whose float32 form keeps float32
+    partial sums -> ``"precise"``.  (``n_src`` no longer matters; kept for callers.)"""
     mode = _precision if mode is None else mode
     if mode != "auto":
         return mode
     if np.dtype(dtype) != np.complex64:
         return "precise"
-    n_src = n_chan if n_src is None else n_src
-    return "mixed" if n_chan <= 8 or (n_chan % 2 == 0 and n_chan <= 16 and n_src <= 4) else "precise"
+    return "mixed" if n_chan <= 8 or (n_chan % 2 == 0 and n_chan <= 16) else "precise"
 
 
 def get_precision():

@@ -209,8 +209,9 @@ class Plan:
         _lib.check(self.lib.oiva_plan_set_cov_splits(self.h, int(n)))
 
     def set_cov_quad(self, enable=True):
-        """float32 covariance pass of a 10/12/14/16-channel plan with <= 4 sources: the four-lanes-per-(bin, frame)
-        vector-ALU kernel (default) or the planar matrix-core kernel; returns whether the former is now active"""
+        """float32 covariance pass of a 10/12/14/16-channel plan: the vector-ALU kernels (default; four lanes per (bin, frame)
+        for <= 4 sources, 32 lanes and all sources in one pass for more) or the planar matrix-core kernel; returns whether
+        a vector-ALU kernel is now active"""
         a = C.c_int()
         _lib.check(self.lib.oiva_plan_set_cov_quad(self.h, 1 if enable else 0, C.byref(a)))
         return bool(a.value)

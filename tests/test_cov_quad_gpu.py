@@ -1,7 +1,9 @@
-"""The four-lanes-per-(bin, frame) covariance kernel of 10 / 12 / 14 / 16-channel plans with few sources
-(csrc/kernels_cov_quad.hip; reference overiva.py:179 and :87): against the oracle on ragged shapes, against the
-matrix-core kernel it replaces, the rules that select it, the default arithmetic of these shapes, and the full-size
-geometry (2048 bins x 4000 frames x 16 channels / 2 sources) through invariants that need no oracle."""
+"""The vector-ALU covariance kernels of 10 / 12 / 14 / 16-channel plans (reference overiva.py:179 and :87): four lanes per
+(bin, frame) for up to 4 sources (csrc/kernels_cov_quad.hip), 32 lanes per (bin, frame) and every source in one pass for
+5..16 (csrc/kernels_cov_half16.hip) -- against the oracle on ragged shapes, against the matrix-core kernel they replace,
+the rules that select them, the default arithmetic of these shapes, and the full-size geometry (2048 bins x 4000 frames x
+16 channels / 2 sources; BASELINE configs[4] is tests/test_gpu_parity.py::test_cfg5_full_size_properties) through invariants
+that need no oracle."""
 import numpy as np
 import pytest
 
@@ -49,9 +51,41 @@ def test_quad_covariances_against_oracle(oa, shape, splits):
     assert np.array_equal(V, np.conj(np.swapaxes(V, -1, -2)))
 
 
+MANY = [(64, 4, 16, 16, "fast"), (163, 19, 16, 9, "mixed"), (150, 18, 10, 5, "fast"), (141, 17, 14, 8, "mixed"),
+        (33, 3, 12, 12, "fast"), (9, 5, 16, 7, "fast"), (200, 7, 16, 12, "mixed"), (17, 1, 14, 14, "mixed")]
+
+
+@pytest.mark.parametrize("splits", [0, 1, 3])
+@pytest.mark.parametrize("shape", MANY, ids=lambda s: "x".join(str(v) for v in s))
+def test_many_source_covariances_against_oracle(oa, shape, splits):
+    """5..16 sources in one pass: an odd number of bins (the last workgroup holds one), a single bin, frames that are no
+    multiple of the 16-frame stage or fewer than one stage, 10 / 12 / 14 channels, source counts that are no multiple of
+    the instantiated 8 / 12 / 16"""
+    T, F, M, K, mode = shape
+    X = orc.synth_mixture(T, F, M, K, seed=4)
+    rinv = np.random.default_rng(5).gamma(2.0, 1.0, (T, K)).astype(np.float32)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision(mode)
+        assert p.set_cov_quad(True)
+        if splits:
+            p.set_cov_splits(min(splits, max(1, T // 16)))
+        p.set_x(X)
+        p.covariance()
+        Cx = p.get_cx()
+        p.t_set_rinv(rinv)
+        p.t_run_weighted_cov()
+        V = p.t_get_v(np.complex128)
+    eC = orc.rel_err(Cx, orc.input_covariance(X.astype(np.complex128)))
+    eV = orc.rel_err(V, orc.weighted_cov_all(X, rinv.astype(np.float64)))
+    print(f"\n[half16] {shape} splits={splits}: V {eV:.1e} Cx {eC:.1e}")
+    assert eV < 2e-7 and eC < 2e-7
+    assert np.array_equal(V, np.conj(np.swapaxes(V, -1, -2)))
+
+
 def test_selection_rules(oa):
-    """one or two sources: every float32 mode; three or four: only with the float64 per-bin algebra; never in `precise`,
-    never for odd channel counts or more than four sources; the switch turns it off"""
+    """one or two sources: every float32 mode; three or four: only with the float64 per-bin algebra (the matrix-core kernel is
+    faster in `fast`); five and more: the 32-lanes-per-(bin, frame) kernel in every float32 mode; never in `precise`, never for
+    odd channel counts; the switch turns both off"""
     def active(M, K, mode, on=True):
         with oa.Plan(64, 20, M, K, "laplace") as p:
             p.set_precision(mode)
@@ -60,7 +94,8 @@ def test_selection_rules(oa):
     assert active(16, 2, "fast") and active(10, 1, "fast") and active(14, 2, "mixed")
     assert active(12, 3, "mixed") and active(16, 4, "mixed")
     assert not active(12, 3, "fast") and not active(16, 4, "fast")
-    assert not active(16, 2, "precise") and not active(11, 2, "fast") and not active(16, 5, "mixed") and not active(8, 2, "fast")
+    assert not active(16, 2, "precise") and not active(11, 2, "fast") and not active(8, 2, "fast")
+    assert active(16, 5, "mixed") and active(16, 16, "fast") and active(12, 12, "mixed")      # many sources: kernels_cov_half16.hip
     assert not active(16, 2, "fast", on=False)
     # the precision set AFTER the switch decides as well
     with oa.Plan(64, 20, 12, 3, "laplace") as p:
@@ -72,7 +107,8 @@ def test_selection_rules(oa):
         assert not p.set_cov_quad(True)
 
 
-@pytest.mark.parametrize("shape", [(163, 19, 16, 2), (150, 18, 10, 2), (141, 33, 14, 1)], ids=lambda s: "x".join(str(v) for v in s))
+@pytest.mark.parametrize("shape", [(163, 19, 16, 2), (150, 18, 10, 2), (141, 33, 14, 1), (128, 9, 16, 16), (120, 12, 12, 7)],
+                         ids=lambda s: "x".join(str(v) for v in s))
 def test_same_iteration_as_the_matrix_core_kernel(oa, shape):
     """5 iterations with either covariance kernel under the same float64 per-bin algebra: the two differ only in the
     rounding of the float32 partial sums"""
@@ -89,15 +125,15 @@ def test_same_iteration_as_the_matrix_core_kernel(oa, shape):
             p.iterate(5)
             W[quad] = p.get_w(np.complex128)
     e = orc.rel_err(W[True], W[False])
-    print(f"\n[quad] {shape}: W quad vs matrix-core {e:.1e}")
-    assert e < 5e-6
+    print(f"\n[quad] {shape}: W vector-ALU vs matrix-core {e:.1e}")
+    assert e < (5e-6 if K <= 4 else 5e-5)       # (many sources: the determined problem amplifies the float32 partials' noise)
 
 
 def test_default_arithmetic_of_10_to_16_channels(oa):
-    """complex64 input: `mixed` where the kernel applies (even channel counts, at most 4 sources), `precise` elsewhere;
+    """complex64 input: `mixed` for even channel counts (the vector-ALU covariance kernels), `precise` for odd ones;
     complex128 input: `precise`"""
     rng = np.random.default_rng(0)
-    for (M, K, dt, want) in ((16, 2, np.complex64, "mixed"), (12, 4, np.complex64, "mixed"), (16, 5, np.complex64, "precise"),
+    for (M, K, dt, want) in ((16, 2, np.complex64, "mixed"), (12, 4, np.complex64, "mixed"), (16, 5, np.complex64, "mixed"), (16, 16, np.complex64, "mixed"), (13, 13, np.complex64, "precise"),
                              (11, 2, np.complex64, "precise"), (16, 2, np.complex128, "precise")):
         X = (rng.standard_normal((40, 6, M)) + 1j * rng.standard_normal((40, 6, M))).astype(dt)
         Y = oa.overiva(X, n_src=K, n_iter=2, proj_back=False)
