@@ -11,12 +11,12 @@ HEAD="--steps 6 --warmup 2 --no-cpu --no-other-mode --no-configs --graph 0"
 
 # bench lines (the default run carries the CPU baseline)
 $B > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
-$B --config cfg5 --no-cpu --precision fast > "$OUT/bench_cfg5.json" 2> "$OUT/bench_cfg5.err"
+$B --config cfg5 --no-cpu > "$OUT/bench_cfg5.json" 2> "$OUT/bench_cfg5.err"
 $B --force-sharded --no-cpu --no-other-mode > "$OUT/bench_sharded_1rank.json" 2> "$OUT/bench_sharded.err"
 
 # kernel-trace statistics of the bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_headline" -o s -- $B --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_cfg5" -o s -- $B --config cfg5 --precision fast --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_cfg5" -o s -- $B --config cfg5 --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
 
 # counters, headline shape, fast mode, eager launches
 i=0
@@ -34,12 +34,12 @@ for c in "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i + 1))
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_precise/p$i" -o p -- $B $HEAD --precision precise > /dev/null 2>&1
 done
-# matrix-core counters, cfg5
+# counters, cfg5 (default arithmetic: the 32-lanes-per-(bin, frame) vector-ALU covariance kernel)
 i=0
-for c in "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
-         "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
+for c in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+         "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i + 1))
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_cfg5/p$i" -o p -- $B --config cfg5 --precision fast $HEAD > /dev/null 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_cfg5/p$i" -o p -- $B --config cfg5 $HEAD > /dev/null 2>&1
 done
 # 16 channels / 2 sources (the four-lanes-per-(bin, frame) covariance kernel), default arithmetic of that shape
 $B --config m16k2 --no-cpu > "$OUT/bench_m16k2.json" 2> "$OUT/bench_m16k2.err"

@@ -111,10 +111,11 @@ def main():
         if "WRITE_SIZE" in cs:
             cs["write_bytes"] = cs["WRITE_SIZE"] * 1024
     json.dump({"note": "rocprofv3 --pmc (4 counters per pass) --kernel-trace, python3 bench.py --config cfg5 --steps 6 --warmup 2 "
-                       "--no-cpu --no-other-mode --graph 0 (fast mode; tools/collect_profiles.sh), MI355X; averages per launch, "
-                       "summed over the chip.  SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs) against GRBM_GUI_ACTIVE / 8 XCDs "
-                       "is the fraction of the kernel the matrix pipes are busy.",
-               "kernels": cfg5}, open(os.path.join(DST, f"{TAG}_cfg5_mfma_pmc.json"), "w"), indent=1)
+                       "--no-cpu --no-other-mode --no-configs --graph 0 (default arithmetic of that shape: mixed; "
+                       "tools/collect_profiles.sh), MI355X; averages per launch, summed over the chip.  SQ *_CYCLES / ACTIVE / WAIT "
+                       "counters are in units of 4 shader cycles; SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs against GRBM_GUI_ACTIVE / 8 "
+                       "XCDs is the fraction of the launch the vector ALU is busy.",
+               "kernels": cfg5}, open(os.path.join(DST, f"{TAG}_cfg5_pmc.json"), "w"), indent=1)
     m16 = counters("pmc_m16k2")
     for k, cs in m16.items():
         if "FETCH_SIZE" in cs:
