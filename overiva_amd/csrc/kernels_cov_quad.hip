@@ -26,7 +26,8 @@
 // workgroup take frames t = 8 i + 2 w + u; their per-lane sums (fp32 chains of T / (4 nsplit) frames) are added in
 // float64 through LDS and stored as float64 packed Hermitian partials, the layout the update kernels read.
 //
-// Measured at 2048 bins x 4000 frames x 16 channels (1.05 GB of X): see DESIGN.md 3.4.
+// Measured at 2048 bins x 4000 frames x 16 channels (1.05 GB of X), two sources: 253-293 us (matrix cores 288-349); what
+// bounds it: DESIGN.md 3.4.1.
 
 #include <cstdint>
 
