@@ -2,5 +2,7 @@
 #include "resident_kernel.inc"
 
 namespace oiva {
-hipError_t launch_resident_m8(hipStream_t s, const ResidentArgs& a, int K, bool update_f64) { return launch_resident_m<8>(s, a, K, update_f64); }
+hipError_t launch_resident_m8(hipStream_t s, const ResidentArgs& a, int K, bool update_f64, bool cov_f64) {
+    return launch_resident_m<8>(s, a, K, update_f64, cov_f64);
+}
 }  // namespace oiva

@@ -106,6 +106,7 @@ struct oiva_plan {
     bool res_on = false;
     void* res_block = nullptr;     // one allocation: parts | vpart | rsum | wpub | flags | ctrl | stamps
     float* res_parts = nullptr;
+    float* res_psum = nullptr;
     double* res_vpart = nullptr;
     double* res_rsum = nullptr;
     float2* res_wpub = nullptr;
@@ -339,7 +340,9 @@ int one_iteration(oiva_plan* p) {
 constexpr int kResidentStampIters = 256;
 
 bool resident_applies(const oiva_plan* p) {
-    return p->res_on && p->res_ok && (p->F == p->F_total || p->res_world > 1) && !p->cov_f64() && !p->raw_weights && !p->wscale_pending;
+    // (the float64 covariance of `precise` exists in the kernel for 4 channels: 32 float64 accumulators per lane)
+    const bool arith_ok = !p->cov_f64() || (p->M == 4 && p->upd_f64());
+    return p->res_on && p->res_ok && (p->F == p->F_total || p->res_world > 1) && arith_ok && !p->raw_weights && !p->wscale_pending;
 }
 
 int resident_alloc(oiva_plan* p) {
@@ -348,17 +351,20 @@ int resident_alloc(oiva_plan* p) {
     const size_t Fp = (size_t)g.NB * 16, NA = (size_t)p->M * p->M, K = p->K;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_parts = up((size_t)2 * g.NB * g.NS * g.TW * K * sizeof(float));
+    const size_t b_psum = up((size_t)2 * g.NS * g.TW * K * sizeof(float));
     const size_t b_vpart = up(((size_t)g.NS * Fp * K * NA + 2) * sizeof(double));
     const size_t b_rsum = up((size_t)g.NB * g.NS * K * sizeof(double));
     const size_t b_wpub = up(Fp * K * p->M * sizeof(float2));
     const size_t b_flags = up(16 * sizeof(unsigned));
     const size_t b_stamps = up((size_t)kResidentStampIters * kResidentStamps * sizeof(unsigned long long));
-    const size_t total = b_parts + b_vpart + b_rsum + b_wpub + b_flags + b_stamps;
+    const size_t total = b_parts + b_psum + b_vpart + b_rsum + b_wpub + b_flags + b_stamps;
     HIP_TRY(hipMalloc(&p->res_block, total));
     HIP_TRY(hipMemsetAsync(p->res_block, 0, total, p->stream));
     char* c = static_cast<char*>(p->res_block);
     p->res_parts = reinterpret_cast<float*>(c);
     c += b_parts;
+    p->res_psum = reinterpret_cast<float*>(c);
+    c += b_psum;
     p->res_vpart = reinterpret_cast<double*>(c);
     c += b_vpart;
     p->res_rsum = reinterpret_cast<double*>(c);
@@ -387,6 +393,7 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     a.what64_valid = p->what64_valid ? 1 : 0;
     a.Cx = p->Cx;
     a.parts = p->res_parts;
+    a.psum = p->res_psum;
     a.vpart = p->res_vpart;
     a.rsum = p->res_rsum;
     a.wpub = p->res_wpub;
@@ -415,7 +422,7 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     a.rank = p->res_rank;
     a.world = p->res_world;
     for (int r = 0; r < OIVA_XCHG_MAX_RANKS; ++r) a.gath[r] = reinterpret_cast<float*>(p->res_gath[r]);
-    HIP_TRY(launch_resident(p->stream, a, p->M, p->K, p->upd_f64()));
+    HIP_TRY(launch_resident(p->stream, a, p->M, p->K, p->upd_f64(), p->cov_f64()));
     p->res_launches++;
     HIP_TRY(hipStreamSynchronize(p->stream));
     unsigned code = 0;

@@ -18,6 +18,7 @@ struct ResidentGeom {
     int lds_bytes = 0;
 };
 constexpr int kResidentRegFrames = 8;
+constexpr int kResidentTwoHopGroups = 40;    // from this many bin groups on, the powers are summed in two hops (reduce-scatter, all-gather)
 constexpr int kResidentMaxTW = 256;          // one thread per frame of the split in the activation phase
 constexpr int kResidentLdsXBytes = 128 << 10;   // LDS given to X (of 160 KB; the rest is reduction scratch and tables)
 
@@ -30,6 +31,7 @@ struct ResidentArgs {
     // exchange buffers in this GPU's memory; every word of them is one agent-scope atomic access that carries its
     // epoch in spare mantissa bits (resident_kernel.inc)
     float* parts;           // [2 (epoch parity)][NB][NS * TW][K] partial source powers
+    float* psum;            // [2 (epoch parity)][NS * TW][K] their sums over the bin groups (two-hop exchange, many bin groups)
     double* vpart;          // [NS][NB * 16][K][M*M] packed partial covariances
     double* rsum;           // [NB][NS][K] sum of the activations r over the split's frames
     float2* wpub;           // [NB * 16][K][M] conj of the demixing vectors, for the power phase
@@ -52,9 +54,10 @@ constexpr int kResidentStamps = 10;
 // true when the shape can run resident on a chip of n_cu compute units (fills g)
 // ns_req > 0 asks for that many frame splits (at most what the chip holds); the result may have fewer when TW rounds up
 bool resident_geometry(int T, int F, int M, int K, int n_cu, int ns_req, ResidentGeom* g);
-hipError_t launch_resident(hipStream_t s, const ResidentArgs& a, int M, int K, bool update_f64);
+// cov_f64: the covariance sums in float64 (the `precise` arithmetic; 4 channels with the float64 update only)
+hipError_t launch_resident(hipStream_t s, const ResidentArgs& a, int M, int K, bool update_f64, bool cov_f64);
 // per-shape instantiations (kernels_resident_m4.hip, kernels_resident_m8.hip)
-hipError_t launch_resident_m4(hipStream_t s, const ResidentArgs& a, int K, bool update_f64);
-hipError_t launch_resident_m8(hipStream_t s, const ResidentArgs& a, int K, bool update_f64);
+hipError_t launch_resident_m4(hipStream_t s, const ResidentArgs& a, int K, bool update_f64, bool cov_f64);
+hipError_t launch_resident_m8(hipStream_t s, const ResidentArgs& a, int K, bool update_f64, bool cov_f64);
 
 }  // namespace oiva

@@ -31,14 +31,15 @@ bool resident_geometry(int T, int F, int M, int K, int n_cu, int ns_req, Residen
     if ((16 + g.NS - 1) / g.NS > slots) return false;
     g.JR = g.J > jl_max ? kResidentRegFrames : 0;
     const int jl = g.J - g.JR;
-    g.lds_bytes = jl * (M / 2) * kBlock * 16 + kResidentMaxTW * K * 4 + 16 * (kBlock + 1) * 4 + kWaves * 8 + 16;
+    g.lds_bytes = jl * (M / 2) * kBlock * 16 + kResidentMaxTW * K * 8 /* weights: float, or double (float64 covariance) */ +
+                  16 * (kBlock + 1) * 4 + kWaves * 8 + 16;
     *out = g;
     return true;
 }
 
-hipError_t launch_resident(hipStream_t s, const ResidentArgs& a, int M, int K, bool update_f64) {
-    if (M == 8) return launch_resident_m8(s, a, K, update_f64);
-    if (M == 4) return launch_resident_m4(s, a, K, update_f64);
+hipError_t launch_resident(hipStream_t s, const ResidentArgs& a, int M, int K, bool update_f64, bool cov_f64) {
+    if (M == 8) return launch_resident_m8(s, a, K, update_f64, cov_f64);
+    if (M == 4) return launch_resident_m4(s, a, K, update_f64, cov_f64);
     return hipErrorInvalidValue;
 }
 

@@ -208,9 +208,9 @@ class _SingleDevice:
         self.precision = precision
         if T * F * M >= self.GRAPH_MIN_ELEMENTS:
             self.plan.use_graph(True)
-        # the loop body as one persistent launch with X on chip wherever the shape qualifies (csrc/resident_kernel.inc);
-        # $OIVA_RESIDENT=0 keeps the four-launch path
-        if precision != "precise" and os.environ.get("OIVA_RESIDENT", "1") != "0" and self.plan.resident_info()["qualifies"]:
+        # the loop body as one persistent launch with X on chip wherever the shape qualifies (csrc/resident_kernel.inc; the
+        # float64 covariance of `precise` exists there for 4 channels); $OIVA_RESIDENT=0 keeps the four-launch path
+        if (precision != "precise" or M == 4) and os.environ.get("OIVA_RESIDENT", "1") != "0" and self.plan.resident_info()["qualifies"]:
             self.plan.set_resident(True)
 
     def set_x(self, X):

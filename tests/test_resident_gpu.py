@@ -121,6 +121,38 @@ def test_resident_shard_against_oracle(oa):
         assert orc.rel_err(W, Wr) < TOL and orc.rel_err(Y, Yr) < TOL
 
 
+@pytest.mark.parametrize("shape", [(1000, 513, 4, 2), (160, 2049, 4, 2), (300, 64, 4, 1), (77, 130, 4, 2)])
+def test_resident_precise_4_channels(oa, shape):
+    """`precise` (float64 covariance sums of exact products, the arithmetic of complex128 input) inside the kernel at 4
+    channels -- the reference's own case (BASELINE configs[0]: 2049 bins x ~160 frames x 4 mics): same W and Y as the
+    four-launch `precise` path to 1e-6 (the two differ in where gamma is applied and in one mantissa bit of the exchanged
+    float32 powers, like the float32 forms), iterations in several calls; and on a mixture both within 1e-5 of the oracle's
+    complex128 result"""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F, M, seed=5)
+    for model in ("laplace", "gauss"):
+        Wr, Yr, info = _run(oa, X, K, model, "precise", 12, True, chunks=[5, 1, 6])
+        W4, Y4, _ = _run(oa, X, K, model, "precise", 12, False)
+        assert info["fallbacks"] == 0 and info["launches"] == 3
+        eW, eY = orc.rel_err(Wr, W4), orc.rel_err(Yr, Y4)
+        print(f"\n[resident] precise {shape} {model}: W {eW:.1e} Y {eY:.1e}")
+        assert eW < 1e-6 and eY < 1e-6
+    Xm = orc.synth_mixture(T, F, M, K, seed=5)
+    Yo, Wo = orc.overiva_staged(Xm.astype(np.complex128), n_src=K, n_iter=10, proj_back=False, return_filters=True)
+    Wr, Yr, info = _run(oa, Xm, K, "laplace", "precise", 10, True)
+    assert info["fallbacks"] == 0 and info["launches"] == 1
+    assert orc.rel_err(Wr, Wo) < TOL and orc.rel_err(Yr, Yo) < TOL
+
+
+def test_precise_stays_on_four_launches_at_8_channels(oa):
+    """128 float64 accumulators do not fit next to X: `precise` with 8 channels keeps the four-launch path even when the
+    switch is on"""
+    T, F, M, K = 300, 64, 8, 2
+    X = orc.synth_iid(T, F, M, seed=1)
+    _, _, info = _run(oa, X, K, "laplace", "precise", 3, True)
+    assert info["launches"] == 0 and info["fallbacks"] == 0
+
+
 def test_resident_gives_up_and_falls_back(oa):
     """a workgroup that never publishes (test hook) = what a grid that is not resident as a whole looks like: every wait
     runs into its time-out, the launch returns without having written W, the plan reports why and runs the call -- and the
@@ -175,3 +207,7 @@ def test_overiva_uses_the_resident_kernel_when_it_applies(oa):
     floor = orc.rel_err(g["W_c64_laplace_20"], g["W_c128_laplace_20"])
     assert orc.rel_err(W, g["W_c128_laplace_20"]) < max(TOL, 1.5 * floor)
     assert oa.last_solver_info()["resident_launches"] >= 2
+    # complex128 input (`precise`) at 4 channels runs in the kernel too
+    Y128, W128 = oa.overiva(g["X"].astype(np.complex128), n_src=K, n_iter=20, proj_back=False, return_filters=True)
+    assert oa.last_solver_info()["precision"] == "precise" and oa.last_solver_info()["resident_launches"] >= 1
+    assert orc.rel_err(W128, g["W_c128_laplace_20"]) < TOL * max(1.0, float(g["amp_laplace_20"]) / 10.0)
