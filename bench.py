@@ -48,6 +48,9 @@ CONFIGS = {
     "cfg5": dict(T=4000, F=2048, M=16, K=16, name="determined AuxIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[4])"),
     "cfg2": dict(T=1000, F=513, M=4, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[1])"),
     "shard8": dict(T=4000, F=256, M=8, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64: one rank's shard of the headline shape at 8 GPUs (BASELINE.json configs[3])"),
+    # BASELINE configs[0] is the reference's own one-shot call (overiva_oneshot.py -a overiva -m 4 -s 2: STFT of 4096-point frames
+    # = 2049 bins x ~160 frames x 4 mics, complex128): the iteration of that shape, in the arithmetic of complex128 input
+    "cfg0": dict(T=160, F=2049, M=4, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, the shape and arithmetic (complex128 input) of the reference's one-shot call (BASELINE.json configs[0])"),
     # not a BASELINE config: 16 channels with few sources, the shape the four-lanes-per-(bin, frame) covariance kernel
     # (csrc/kernels_cov_quad.hip) exists for; timed in its default arithmetic (`mixed`)
     "m16k2": dict(T=4000, F=2048, M=16, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (16 channels, few sources)"),
@@ -262,7 +265,7 @@ def _secondary_config(torch, oa, dev, name, args):
     shape qualifies, the X-resident kernel; the faster one is `value`"""
     c = CONFIGS[name]
     shape = (c["T"], c["F"], c["M"], c["K"])
-    mode = "mixed" if c["M"] <= 8 or name == "m16k2" else args.cfg5_precision
+    mode = "precise" if name == "cfg0" else ("mixed" if c["M"] <= 8 or name == "m16k2" else args.cfg5_precision)
     X = synth_x_device(torch, dev, 0, c["F"], shape[:3])
     torch.cuda.synchronize()
     out = {"workload": c["name"].format(**c), "precision": mode, "steps": args.steps, "warmup": args.warmup}
@@ -272,7 +275,7 @@ def _secondary_config(torch, oa, dev, name, args):
     plan.close()
     cov_ms = stages["weighted_cov"] / args.steps
     _, roof = _cov_roofline(shape, mode, cov_ms)
-    if name == "cfg2":
+    if name in ("cfg2", "cfg0"):
         roof["note"] = "16 MB of X: resident in L2 / Infinity Cache, the pass is launch- and latency-bound, not a roofline claim"
     out["four_launch"] = {"value": args.steps / dt, "unit": "iterations/s", "ms_per_step": dt / args.steps * 1e3,
                           "stage_ms_per_step": {k: v / args.steps for k, v in stages.items()}, "roofline": roof}
@@ -358,7 +361,7 @@ def run_single(args):
     torch.cuda.empty_cache()
     if not args.no_configs and args.config == "headline":
         out["configs"] = {}
-        for name in ("cfg2", "shard8", "cfg5", "m16k2"):
+        for name in ("cfg0", "cfg2", "shard8", "cfg5", "m16k2"):
             try:
                 out["configs"][name] = _secondary_config(torch, oa, dev, name, args)
             except Exception as e:  # a secondary shape must not cost the headline line
@@ -693,7 +696,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="0: eager; 1 (default): hipGraph replay on a single GPU, eager when sharded; 2: graph also when sharded")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-configs", action="store_true", help="skip the secondary configs (cfg2, shard8, cfg5, m16k2) of the N = 1 line")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary configs (cfg0, cfg2, shard8, cfg5, m16k2) of the N = 1 line")
     ap.add_argument("--repeats", type=int, default=4, help="extra measurements of the same K steps for value_median (N = 1)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="headline",
                     help="headline: BASELINE.json configs[2] (the metric's workload); cfg5: configs[4], 16 mics / 16 sources; "
