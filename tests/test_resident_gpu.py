@@ -78,11 +78,13 @@ def test_resident_matches_reference_fixtures(oa, path, model, mode):
     assert checked > 0
 
 
-@pytest.mark.parametrize("shape", [(1000, 513, 4, 2), (4000, 256, 8, 2), (4000, 250, 8, 1), (3999, 256, 4, 2), (700, 96, 8, 2)])
+@pytest.mark.parametrize("shape", [(1000, 513, 4, 2), (4000, 256, 8, 2), (4000, 250, 8, 1), (3999, 256, 4, 2), (700, 96, 8, 2),
+                                   (160, 2049, 4, 2), (235, 2049, 4, 1), (200, 800, 8, 2), (120, 1000, 8, 1)])
 @pytest.mark.parametrize("mode", ["fast", "mixed"])
 def test_resident_equals_four_launch_path(oa, shape, mode):
     """BASELINE configs[1], one rank's shard of the headline shape at 8 GPUs (full and ragged), 4 channels with 16 frames
-    per lane in LDS, a small-split shape: same W and Y as the four-launch path to 1e-6 (the two differ in where gamma is
+    per lane in LDS, a small-split shape, and shapes with 40 and more bin groups -- the reference's own 2049 bins among them
+    -- whose powers are exchanged in two hops: same W and Y as the four-launch path to 1e-6 (the two differ in where gamma is
     applied and in one mantissa bit of the exchanged parts), also when the iterations come in several calls"""
     T, F, M, K = shape
     X = orc.synth_iid(T, F, M, seed=3)
@@ -181,6 +183,27 @@ def test_resident_gives_up_and_falls_back(oa):
         p.iterate(2)
         assert p.resident_info()["fallbacks"] == 1 and p.resident_info()["launches"] == 2
         assert np.all(np.isfinite(p.get_w()))
+
+
+def test_two_hop_exchange_gives_up_too(oa):
+    """the same with 44 bin groups (the reduce-scatter / all-gather exchange of the powers has its own waits): a workgroup
+    that never publishes its share of the column's sums stalls every workgroup of the column; the launch gives up, changes
+    nothing, and the plan continues on the four-launch path"""
+    T, F, M, K = 120, 700, 4, 2
+    X = orc.synth_iid(T, F, M, seed=9)
+    W4, Y4, _ = _run(oa, X, K, "laplace", "mixed", 5, False)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision("mixed")
+        p.set_x(X)
+        p.covariance()
+        p.set_w(None)
+        p.set_resident(True)
+        assert p.resident_info()["bin_groups"] >= 40
+        p.resident_debug(timeout_ms=20, stall_block=1)
+        p.iterate(5)
+        info = p.resident_info()
+        assert info["fallbacks"] == 1 and info["enabled"] == 0 and info["last_give_up_code"] != 0
+        assert np.array_equal(p.get_w(np.complex128), W4) and np.array_equal(p.demix(False), Y4)
 
 
 def test_shapes_that_do_not_qualify(oa):
