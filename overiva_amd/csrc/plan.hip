@@ -136,6 +136,15 @@ int pick_splits(int capacity, int blocks_per_split, int T, int min_frames) {
     return ns;
 }
 
+// Kernels with four frame phases per workgroup, float64 per-bin algebra behind them (`mixed`): 8 frame splits on a long
+// frame axis, 4 on a short one (their float32 chains are then T / 32 resp. T / 16 frames); on a short axis never more than
+// one round of workgroups (a workgroup's fixed costs dominate there) or splits of fewer than 16 frames.
+int mixed_min_splits(int capacity, int blocks_per_split, int T) {
+    if (T >= 1024) return 8;       // (a second round of workgroups costs little there: +18 us of 270 at 2048 x 4000 x 16 / 2)
+    const int one_round = std::max(1, capacity / std::max(1, blocks_per_split));
+    return std::max(1, std::min(std::min(4, one_round), T / 16));
+}
+
 void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     CovGeom g;
     // float64, 8 channels: two lanes per (bin, frame), 32 bins per workgroup (kernels_cov_pair64.hip); else 16 bins
@@ -156,14 +165,16 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         g.quad = 1;
         g.kc = cov_quad_sources_per_pass(p->K);
         if (nsplit <= 0) {
-            nsplit = std::min(32, pick_splits(p->n_cu * 2, g.nbg * ceil_div(p->K, g.kc), p->T, 128));
+            const int blocks = g.nbg * ceil_div(p->K, g.kc);
+            nsplit = std::min(32, pick_splits(p->n_cu * 2, blocks, p->T, 64));
             // only 4 frame phases per workgroup: a lane's float32 chain is T / (4 nsplit) frames, four times that of the
             // 8-channel kernel at equal splits, and the error of the result grows linearly with it (measured against
             // the reference's own complex64 floor, 16 channels / 2 sources x 20 iterations: T = 4000: 4 splits 0.8-1.0
             // floors, 8 splits 0.5-0.6, 16 splits 0.3; T = 163: 1 split 1.4, 4 splits 0.8, 8 splits 0.6).  With the
             // float64 per-bin algebra (`mixed`, the default arithmetic of these shapes) the chains are what is left of
             // the error, so that mode takes 8 splits (+18 us on the pass, +8 us in the update at 2048 x 4000 x 16 / 2).
-            if (p->upd_f64()) nsplit = std::max(nsplit, std::min(8, std::max(1, p->T / 8)));
+            // ... as long as that is still one round of workgroups (few frames: 4 splits = chains of T / 16, 0.8 floors)
+            if (p->upd_f64()) nsplit = std::max(nsplit, mixed_min_splits(p->n_cu * 2, blocks, p->T));
         }
         g.tc = round_up(ceil_div(p->T, nsplit), 8);
         g.nsplit = ceil_div(p->T, g.tc);
@@ -205,7 +216,9 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         // one round: the grid is what the chip holds at once (CUs x resident workgroups); every workgroup pays a
         // fixed cost (gamma prologue, ring fill, epilogue), so fewer, longer workgroups win as long as the chip
         // is full, and 1.5 rounds run as long as 2
-        nsplit = pick_splits(p->n_cu * bpc, g.nbg * nz, p->T, 128);
+        // (at least 64 frames per split: at the reference's 160-235 frames a floor of 128 left the chip to one split --
+        //  2049 x 235 x 8 / 2: 1 split 18.9 / 29.2 us (float32 / float64), 3 splits 14.7 / 16.8)
+        nsplit = pick_splits(p->n_cu * bpc, g.nbg * nz, p->T, 64);
         // the update kernel adds the nsplit partials of every matrix element in one round of loads per 16 splits
         // (sum_vpart); more than 32 splits cost more there than the fuller grid saves here (measured on a
         // 256-bin shard: 16 splits 25.2 + 8.0 us, 28 splits 21.4 + 9.2 us, 42 splits 25.5 + 10.3 us)
@@ -215,7 +228,7 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         nsplit = std::min(nsplit, cap);
         // four frame phases per workgroup instead of 16: float32 chains four times as long at equal splits; with the
         // float64 per-bin algebra behind it the pass takes at least 8 splits (see the 10..16-channel kernel above)
-        if (g.pair32 && p->upd_f64()) nsplit = std::max(nsplit, std::min(8, std::max(1, p->T / 8)));
+        if (g.pair32 && p->upd_f64()) nsplit = std::max(nsplit, mixed_min_splits(p->n_cu * bpc, g.nbg * nz, p->T));
     }
     g.tc = round_up(ceil_div(p->T, nsplit), quantum);
     g.nsplit = ceil_div(p->T, g.tc);
