@@ -166,7 +166,7 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         g.kc = cov_quad_sources_per_pass(p->K);
         if (nsplit <= 0) {
             const int blocks = g.nbg * ceil_div(p->K, g.kc);
-            nsplit = std::min(32, pick_splits(p->n_cu * 2, blocks, p->T, 64));
+            nsplit = std::min(32, pick_splits(p->n_cu * 2, blocks, p->T, p->T >= 1024 ? 128 : 64));
             // only 4 frame phases per workgroup: a lane's float32 chain is T / (4 nsplit) frames, four times that of the
             // 8-channel kernel at equal splits, and the error of the result grows linearly with it (measured against
             // the reference's own complex64 floor, 16 channels / 2 sources x 20 iterations: T = 4000: 4 splits 0.8-1.0
@@ -216,9 +216,11 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         // one round: the grid is what the chip holds at once (CUs x resident workgroups); every workgroup pays a
         // fixed cost (gamma prologue, ring fill, epilogue), so fewer, longer workgroups win as long as the chip
         // is full, and 1.5 rounds run as long as 2
-        // (at least 64 frames per split: at the reference's 160-235 frames a floor of 128 left the chip to one split --
-        //  2049 x 235 x 8 / 2: 1 split 18.9 / 29.2 us (float32 / float64), 3 splits 14.7 / 16.8)
-        nsplit = pick_splits(p->n_cu * bpc, g.nbg * nz, p->T, 64);
+        // (on a short frame axis at least 64 frames per split instead of 128: at the reference's 160-235 frames the floor of
+        //  128 left the chip to one split -- 2049 x 235 x 8 / 2: 1 split 18.9 / 29.2 us (float32 / float64), 3 splits 14.7 /
+        //  16.8.  On a long axis the floor of 128 stays: a 256-bin shard of 4000 frames takes 28 splits in 20.4 us, 32 splits
+        //  -- exactly the chip's 512 workgroup slots, which the dispatcher does not fill evenly -- 26.3)
+        nsplit = pick_splits(p->n_cu * bpc, g.nbg * nz, p->T, p->T >= 1024 ? 128 : 64);
         // the update kernel adds the nsplit partials of every matrix element in one round of loads per 16 splits
         // (sum_vpart); more than 32 splits cost more there than the fuller grid saves here (measured on a
         // 256-bin shard: 16 splits 25.2 + 8.0 us, 28 splits 21.4 + 9.2 us, 42 splits 25.5 + 10.3 us)
@@ -257,16 +259,17 @@ void choose_pow_geom(oiva_plan* p, int nsplit_req) {
         // x 4000 frames on the kernel itself and on the pure-read form of its geometry (tools/membench.hip, pattern P):
         // 8 channels 12 splits (384 workgroups) 88-90 us, 16: 91, 24: 92, 8: 106 (four steps in flight and 24 splits, as in
         // round 1: 94-96 us); 4 channels 24 splits 40.7 us, 12: 46; 2 channels 24 splits 21.8, 12: 35; 16 channels / 2
-        // sources 6 splits 172 us, 12: 234.  More resident waves thrash the 32 KB L1, fewer expose HBM latency.  At
-        // least 64 frames (16 steps per wave) per workgroup: each one loads its W first (256-bin shard: 62 splits
-        // 13.5 us, 167 splits 15.9 us).
+        // sources 6 splits 172 us, 12: 234.  More resident waves thrash the 32 KB L1, fewer expose HBM latency.  Each
+        // workgroup loads its W first (256-bin shard: 62 splits 13.5 us, 167 splits 15.9 us).
         // (counted per source pass: with 8 sources in two passes, 12 splits 112 us, 6 splits 127-137 us)
         // ONE source per pass halves the arithmetic per byte and a wave runs through its two steps in flight before the next
         // ones arrive: twice the workgroups (8 channels / 1 source: 12 splits 111 us, 24 splits 92.5; with 2-4 sources 24
         // splits measure the same as 12)
         // (not beyond 8 channels: 16 channels / 1 source 6 splits 226 us, 12 splits -- 1.5 rounds of workgroups -- 276)
         const int per_cu_x12 = (g.kp == 1 && p->M <= 8) ? 24 : 12;
-        nsplit = pick_splits(std::max(p->n_cu / 2, p->n_cu * per_cu_x12 / std::max(p->M, 1)), g.nb, p->T, 64);
+        // (at least 32 frames per workgroup: with 64, 2049 x 235 x 8 / 2 ran 3 splits in 16.0 us where 6-8 take 11.9-12.1,
+        //  2049 x 160 x 4 / 2 2 splits in 12.0 us where 5-8 take 8.2-8.4)
+        nsplit = pick_splits(std::max(p->n_cu / 2, p->n_cu * per_cu_x12 / std::max(p->M, 1)), g.nb, p->T, 32);
     }
     int tcp = round_up(ceil_div(p->T, nsplit), 4);
     tcp = std::min(std::max(tcp, 4), kPowMaxFrames);
