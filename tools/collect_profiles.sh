@@ -15,7 +15,10 @@ $B --config cfg5 --no-cpu > "$OUT/bench_cfg5.json" 2> "$OUT/bench_cfg5.err"
 $B --force-sharded --no-cpu --no-other-mode > "$OUT/bench_sharded_1rank.json" 2> "$OUT/bench_sharded.err"
 
 # kernel-trace statistics of the bench command
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_headline" -o s -- $B --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
+# (the headline workload alone, so that a kernel's average is the average over ITS launches of that workload: the secondary
+#  configs run the same kernel instantiations on other shapes -- those go to stats_configs)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_headline" -o s -- $B --steps 20 --warmup 3 --no-cpu --no-configs > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_configs" -o s -- $B --steps 20 --warmup 3 --no-cpu --no-other-mode > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_cfg5" -o s -- $B --config cfg5 --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
 
 # counters, headline shape, fast mode, eager launches

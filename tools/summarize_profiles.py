@@ -59,7 +59,8 @@ def main():
         if os.path.exists(path):
             line = [l for l in open(path).read().splitlines() if l.startswith("{")][-1]
             json.dump(json.loads(line), open(os.path.join(DST, f"{TAG}_{out}"), "w"), indent=1)
-    stats("stats_headline", f"{TAG}_kernel_stats.csv")
+    stats("stats_headline", f"{TAG}_kernel_stats.csv")                 # the headline workload (all three arithmetic modes)
+    stats("stats_configs", f"{TAG}_configs_kernel_stats.csv")          # the same command with its secondary configs
     stats("stats_cfg5", f"{TAG}_cfg5_kernel_stats.csv")
     stats("stats_m16k2", f"{TAG}_m16k2_kernel_stats.csv")
     stats("stats_resident", f"{TAG}_resident_shard8_kernel_stats.csv")
