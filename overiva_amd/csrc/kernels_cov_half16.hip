@@ -209,6 +209,19 @@ __global__ __launch_bounds__(kBlock, 2) void cov_half16_kernel(const float2* __r
     float* lds = reinterpret_cast<float*>(ring);
     constexpr int NACC = 2 * NP * kH16Entries * 2;
     const int NA = M * M;
+    // thread tid sums accumulator wave + 4 v (+ r0) of LANE `lane` in every round: the packed positions of that lane's five
+    // entries are computed once (-1: dropped -- below the diagonal of a diagonal block, or a channel >= M)
+    int pos[kH16Entries];
+    bool offdiag[kH16Entries];
+#pragma unroll
+    for (int ent = 0; ent < kH16Entries; ++ent) {
+        int ci, di;
+        h16_entry(e, ent, &ci, &di);
+        offdiag[ent] = ci < di;
+        pos[ent] = (di < M && ci <= di) ? (ci == di ? ci : herm_pair_index(M, ci, di)) : -1;
+    }
+    const int fo = f0 + h;
+    double* const vb = Vpart + (((size_t)blockIdx.y * F + (fo < F ? fo : F - 1)) * K + k0) * NA;
 #pragma unroll
     for (int r0 = 0; r0 < NACC; r0 += kH16Chunk) {
         __syncthreads();
@@ -221,19 +234,21 @@ __global__ __launch_bounds__(kBlock, 2) void cov_half16_kernel(const float2* __r
         __syncthreads();
 #pragma unroll
         for (int v = 0; v < kH16Chunk * 64 / kBlock; ++v) {
-            const int idx = tid + kBlock * v;
-            const int aa = idx >> 6, l = idx & 63;
+            const int aa = wave + 4 * v;            // == (tid + kBlock * v) >> 6; the lane is this thread's own
             double s = 0.;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) s += (double)lds[aa * kH16LdsStride + w * 64 + l];
+            for (int w = 0; w < kWaves; ++w) s += (double)lds[aa * kH16LdsStride + w * 64 + lane];
             const int n = r0 + aa;
-            const int src = n / (2 * kH16Entries), ent = (n % (2 * kH16Entries)) >> 1, im = n & 1;
-            int ci, di;
-            h16_entry(l & 31, ent, &ci, &di);
-            const int fo = f0 + (l >> 5);
-            const bool keep = di < M && (ci < di || (ci == di && im == 0)) && fo < F && k0 + src < K && (!UNIT || src == 0);
-            if (keep)
-                Vpart[(((size_t)blockIdx.y * F + fo) * K + k0 + src) * NA + (ci == di ? ci : herm_pair_index(M, ci, di) + im)] = s;
+            const int src = n / (2 * kH16Entries), rem = n % (2 * kH16Entries), ent = rem >> 1, im = rem & 1;
+            int pe = pos[0];
+            bool od = offdiag[0];
+#pragma unroll
+            for (int x = 1; x < kH16Entries; ++x) {
+                pe = ent == x ? pos[x] : pe;
+                od = ent == x ? offdiag[x] : od;
+            }
+            const bool keep = pe >= 0 && (im == 0 || od) && fo < F && k0 + src < K && (!UNIT || src == 0);
+            if (keep) vb[(size_t)src * NA + pe + im] = s;
         }
     }
 }
