@@ -1015,9 +1015,11 @@ int oiva_plan_iterate_timed(oiva_plan* p, int n, float* total_ms, float* per_ker
             // the covariance stage is reported as the duration of its kernel proper (events attached to the dispatch),
             // which is what the roofline is about and what rocprofv3 shows; the bracketing events add ~3 us of gaps
             float kms = 0.f;
-            // (9..16 channels: the stage is two launches -- the weights pre-pass and the matrix-core kernel -- and keeps its
-            //  bracketed time, so that the stages still add up to the total)
-            if (s == 2 && p->M <= 8 && kev[2 * it] && kev[2 * it + 1] && hipEventElapsedTime(&kms, kev[2 * it], kev[2 * it + 1]) == hipSuccess &&
+            // (where the stage is two launches -- a weights pre-pass in front of the kernel: 9..16 channels, the float64 kernel
+            //  of 8 channels, 8 channels with three or more sources -- it keeps its bracketed time, so that the stages still add
+            //  up to the total)
+            const bool one_launch = p->M <= 8 && !p->cov.pair32 && !(p->cov_f64() && cov_pair64_supported(p->M));
+            if (s == 2 && one_launch && kev[2 * it] && kev[2 * it + 1] && hipEventElapsedTime(&kms, kev[2 * it], kev[2 * it + 1]) == hipSuccess &&
                 kms > 0.f && kms <= ms)
                 ms = kms;
             else if (s == 2)
