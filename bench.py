@@ -221,9 +221,12 @@ def _cov_roofline(shape, mode, cov_ms):
             kname = f"cov_pair64_kernel<{min(k, 2)}, false>" if m == 8 else f"cov_kernel<{m}, {min(k, 2)}, false, double>"
         else:
             kname = "cov_pair32_kernel<false>" if m == 8 and k >= 3 else f"cov_dma_kernel<{m}, {min(k, 2)}>"
-        return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, overiva.py:179)",
-                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                       "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms}
+        roof = {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, overiva.py:179)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms}
+        if kname.startswith(("cov_pair64", "cov_pair32")):
+            roof["note"] = "avg_launch_ms is the event-bracketed stage: the weights pre-pass (~4 us) + the kernel + the gaps of the bracketing events"
+        return kname, roof
     if m % 2 == 0 and mode != "precise" and (k <= 2 or (k <= 4 and mode == "mixed")):
         # the Hermitian half on the vector ALU, four lanes per (bin, frame): one pass over X per two sources
         bytes_cov = cov_algorithmic_bytes(t, f, m, k) + (-(-k // 2) - 1) * 8 * t * f * m
