@@ -251,6 +251,22 @@ def _cov_roofline(shape, mode, cov_ms):
                        "vector_alu": {"packed_wave_instructions_per_launch": instr, "issue_floor_ms": floor_ms, "frac_of_issue_floor": floor_ms / cov_ms},
                        "note": "NOT memory-bound: the vector ALU's packed-fp32 issue rate bounds it (vector_alu); the fp32 matrix cores "
                                "have the same peak and the planar form needs 2.8x the multiply-adds (it measured 1.69 ms at 16 x 16)"}
+    if m % 2 == 0 and mode == "precise" and k >= 3:
+        # the same lanes with float64 sums of exact products, four or eight sources per pass: bound by the float64 issue rate of
+        # the vector ALU (14 conversions + 20 + 10 * sources float64 instructions per lane and frame)
+        ns = 4 if k <= 4 else 8
+        passes = -(-k // ns)
+        bytes_cov = cov_algorithmic_bytes(t, f, m, k) + (passes - 1) * 8 * t * f * m
+        instr = 32.0 * (14 + 20 + 10 * ns) * passes * t * f / 64
+        floor_ms = instr / 1024 * 2.2e-6                       # 2.2 ns per float64 instruction and SIMD (tools/pkbench.hip)
+        kname = f"cov_half16f64_kernel<{ns}>"
+        return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance, {ns} sources per pass over X, overiva.py:179)",
+                       "achieved": bytes_cov / (cov_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": bytes_cov / (cov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_cov,
+                       "avg_launch_ms": cov_ms,
+                       "vector_alu": {"f64_wave_instructions_per_launch": instr, "issue_floor_ms": floor_ms, "frac_of_issue_floor": floor_ms / cov_ms},
+                       "note": "NOT memory-bound: the vector ALU's float64 issue rate bounds it (vector_alu); the fp64 matrix-core form "
+                               "it replaces measured 3.1 ms at 16 x 16"}
     naive = 8.0 * k * m * m * t * f            # complex MACs counted as 8 real flops
     issued = 6.0 * k * m * m * t * f           # what the planar form issues: 3 MFMAs of 16x16x4 per 4 frames and source
     kname = "cov_mfma16_kernel<double, 16>" if mode == "precise" else "cov_mfma16_kernel<float, 16>"

@@ -392,6 +392,8 @@ int cov_sources_per_pass(int M, int K, bool f64) {
 hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                       void* Vpart, bool f64, int T, int F, int M, int K, const CovGeom& g) {
     if (M > 8 && g.half16 && !f64) return launch_cov_half16(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
+    if (M > 8 && g.half16 && f64 && R != nullptr)
+        return launch_cov_half16_f64(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
     if (M > 8 && g.quad && !f64) return launch_cov_quad(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
     if (M > 8) return launch_cov_mfma(s, X, R, Wt, wscale, model, raw, Vpart, f64, T, F, M, K, g.nsplit, g.tc);
     if (!f64 && g.pair32) return launch_cov_pair32(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);

@@ -253,6 +253,181 @@ __global__ __launch_bounds__(kBlock, 2) void cov_half16_kernel(const float2* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// float64 form (the `precise` arithmetic, OIVA_PREC_COV_F64) of the same decomposition for more than 4 sources: float64 sums of
+// exact float64 products, EIGHT sources per pass (80 float64 accumulators per lane).  The fp64 matrix-core kernel it
+// replaces there (kernels_cov_mfma.hip) spends 768 multiply-adds per frame and source on a pipe that sustains 44 TFLOP/s;
+// this one 14 conversions + 20 + 10 K float64 vector instructions per lane and frame at 60 TFLOP/s peak.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kH64WeightStride = 16;                    // doubles per row of the float64 weight table
+constexpr int kH64Chunk = kH16Chunk / 2;                // doubles per LDS round of the epilogue (same scratch bytes)
+
+// Final float64 weights: Wt[t][k] = 1 / max(r[t,k] / gamma_k, eps) (overiva.py:158-173), columns >= K and row T zero
+__global__ __launch_bounds__(kBlock) void h64_weights_kernel(const float* __restrict__ R, double* __restrict__ Wt, float* __restrict__ wscale,
+                                                             int model, int raw, int T, int K) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= (T + 1) * kH64WeightStride) return;
+    const int t = e / kH64WeightStride, k = e % kH64WeightStride;
+    double w = 0.;
+    if (t < T && k < K) {
+        const double gamma = (raw & 1) ? 1. : gamma_of(R, T, K, k);
+        double rn = (double)R[(size_t)t * K + k] / gamma;
+        rn = rn < (double)kEpsR ? (double)kEpsR : rn;          // a NaN stays NaN, like r[r < eps] = eps in the reference
+        w = 1. / rn;
+        if (t == 0 && wscale != nullptr && !(raw & 1))
+            wscale[k] = model == OIVA_MODEL_LAPLACE ? (float)gamma : (float)sqrt(gamma);   // overiva.py:163 / :167
+    }
+    Wt[e] = w;
+}
+
+template <int NS, int OFF, bool WAIT>
+__device__ __forceinline__ void h64_frame(double (&accr)[NS][kH16Entries], double (&acci)[NS][kH16Entries],
+                                          const unsigned (&ad)[4], const double (&w)[NS], double (&wn)[NS],
+                                          const double* wpn) {
+    v2f row, xrow, xcol;
+    float4 c01, c23;
+    h16_read<OFF, WAIT>(ad, row, c01, c23, xrow, xcol);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) wn[q] = wpn[q];          // the next frame's weights: wave-uniform scalar loads
+    __builtin_amdgcn_sched_barrier(0);
+    const double ar[kH16Entries] = {row.x, row.x, row.x, row.x, xrow.x}, ai[kH16Entries] = {row.y, row.y, row.y, row.y, xrow.y};
+    const double br[kH16Entries] = {c01.x, c01.z, c23.x, c23.z, xcol.x}, bi[kH16Entries] = {c01.y, c01.w, c23.y, c23.w, xcol.y};
+#pragma unroll
+    for (int i = 0; i < kH16Entries; ++i) {
+        const double pre = fma(ar[i], br[i], ai[i] * bi[i]);       // x_c conj(x_d)
+        const double pim = fma(ai[i], br[i], -(ar[i] * bi[i]));
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            accr[q][i] = fma(w[q], pre, accr[q][i]);
+            acci[q][i] = fma(w[q], pim, acci[q][i]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NS>
+__global__ __launch_bounds__(kBlock, NS == 8 ? 2 : 4) void cov_half16f64_kernel(const float2* __restrict__ X, const double* __restrict__ Wt,
+                                                                  double* __restrict__ Vpart, int T, int F, int M, int K, int tc) {
+    constexpr int kRingBytes = kWaves * kH16Stages * kH16Stage;
+    constexpr int kScratchBytes = (int)sizeof(double) * kH64Chunk * kH16LdsStride;
+    __shared__ float4 ring[(kRingBytes > kScratchBytes ? kRingBytes : kScratchBytes) / 16 + 1];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int e = lane & 31;
+    const int f0 = blockIdx.x * 2;
+    const int k0 = blockIdx.z * NS;
+    const int t_begin = blockIdx.y * tc;
+    const int t_end = min(T, t_begin + tc);
+    const int nstages = (t_end - t_begin + 4 * kH16Frames - 1) / (4 * kH16Frames);
+
+    double accr[NS][kH16Entries], acci[NS][kH16Entries];
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < kH16Entries; ++i) accr[q][i] = acci[q][i] = 0.;
+
+    char* wring = reinterpret_cast<char*>(ring) + wave * (kH16Stages * kH16Stage);       // wave-uniform
+    const int run_pieces = min(2, F - f0) * M / 2;
+    const unsigned piece_off = (unsigned)min(lane & 15, run_pieces - 1) * 16u;
+    const int lane_frame = 4 * (lane >> 4);
+    const char* xbytes = reinterpret_cast<const char*>(X);
+    const size_t row_bytes = (size_t)F * M * 8;
+    const char* run0 = xbytes + (size_t)f0 * M * 8 + piece_off;
+    auto issue = [&](int i, int s) {
+        const int t = t_begin + wave + 4 * kH16Frames * i + lane_frame;
+        const int tcl = min(i < nstages ? t : T - 1, T - 1);
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(run0 + (size_t)tcl * row_bytes), (lvoid_t*)(wring + s * kH16Stage), 16, 0, 0);
+    };
+    int ci0, di0, cix, dix;
+    h16_entry(e, 0, &ci0, &di0);
+    h16_entry(e, 4, &cix, &dix);
+    const unsigned lbase = (unsigned)(uintptr_t)wring + (unsigned)(h * M * 8);
+    const unsigned ad[4] = {lbase + 8u * ci0, lbase + 8u * di0, lbase + 8u * cix, lbase + 8u * dix};
+
+    auto wrow = [&](int i, int u) -> const double* {      // frames past the split: the zeroed row T
+        const int t = t_begin + wave + 4 * (kH16Frames * i + u);
+        return Wt + (size_t)(t < t_end ? t : T) * kH64WeightStride + k0;
+    };
+    double wa[NS], wb[NS];
+#define OIVA_H64_FRAME(I, S, U, W, WN, IN, UN) \
+    h64_frame<NS, (S) * kH16Stage + (U) * kH16Slot, (U) == 0>(accr, acci, ad, W, WN, wrow(IN, UN));
+#define OIVA_H64_STAGE(I, S)                  \
+    OIVA_H64_FRAME(I, S, 0, wa, wb, I, 1)     \
+    OIVA_H64_FRAME(I, S, 1, wb, wa, I, 2)     \
+    OIVA_H64_FRAME(I, S, 2, wa, wb, I, 3)     \
+    OIVA_H64_FRAME(I, S, 3, wb, wa, (I) + 1, 0)
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
+    {
+        const double* wp0 = wrow(0, 0);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) wa[q] = wp0[q];
+    }
+    int i = 0;
+    for (; i + 4 <= nstages; i += 4) {
+        issue(i + 3, 3); OIVA_H64_STAGE(i, 0)
+        issue(i + 4, 0); OIVA_H64_STAGE(i + 1, 1)
+        issue(i + 5, 1); OIVA_H64_STAGE(i + 2, 2)
+        issue(i + 6, 2); OIVA_H64_STAGE(i + 3, 3)
+    }
+    if (i < nstages) { issue(i + 3, 3); OIVA_H64_STAGE(i, 0) }
+    if (i + 1 < nstages) { issue(i + 4, 0); OIVA_H64_STAGE(i + 1, 1) }
+    if (i + 2 < nstages) { issue(i + 5, 1); OIVA_H64_STAGE(i + 2, 2) }
+#undef OIVA_H64_STAGE
+#undef OIVA_H64_FRAME
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // the four waves added in fixed order, rounds of 8 doubles; accumulator n = source * 10 + entry * 2 + (re | im)
+    double* lds = reinterpret_cast<double*>(ring);
+    constexpr int NACC = NS * kH16Entries * 2;
+    const int NA = M * M;
+    int pos[kH16Entries];
+    bool offdiag[kH16Entries];
+#pragma unroll
+    for (int ent = 0; ent < kH16Entries; ++ent) {
+        int ci, di;
+        h16_entry(e, ent, &ci, &di);
+        offdiag[ent] = ci < di;
+        pos[ent] = (di < M && ci <= di) ? (ci == di ? ci : herm_pair_index(M, ci, di)) : -1;
+    }
+    const int fo = f0 + h;
+    double* const vb = Vpart + (((size_t)blockIdx.y * F + (fo < F ? fo : F - 1)) * K + k0) * NA;
+#pragma unroll
+    for (int r0 = 0; r0 < NACC; r0 += kH64Chunk) {
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < kH64Chunk; ++a) {
+            const int n = r0 + a < NACC ? r0 + a : 0;       // compile-time
+            const int q = n / (2 * kH16Entries), ent = (n % (2 * kH16Entries)) / 2;
+            lds[a * kH16LdsStride + tid] = (n & 1) ? acci[q][ent] : accr[q][ent];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < kH64Chunk * 64 / kBlock; ++v) {
+            const int aa = wave + 4 * v;
+            double s = 0.;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) s += lds[aa * kH16LdsStride + w * 64 + lane];
+            const int n = r0 + aa;
+            const int src = n / (2 * kH16Entries), rem = n % (2 * kH16Entries), ent = rem >> 1, im = rem & 1;
+            int pe = pos[0];
+            bool od = offdiag[0];
+#pragma unroll
+            for (int x = 1; x < kH16Entries; ++x) {
+                pe = ent == x ? pos[x] : pe;
+                od = ent == x ? offdiag[x] : od;
+            }
+            const bool keep = pe >= 0 && (im == 0 || od) && fo < F && k0 + src < K && n < NACC;
+            if (keep) vb[(size_t)src * NA + pe + im] = s;
+        }
+    }
+}
+
 }  // namespace
 
 bool cov_half16_supported(int M, int K) { return M >= 10 && M <= 16 && M % 2 == 0 && K >= 1 && K <= 16; }
@@ -276,6 +451,26 @@ hipError_t launch_cov_half16(hipStream_t s, const float2* X, const float* R, flo
     if (K <= 12)
         return launch_dominant(cov_half16_kernel<6, false>, grid, block, 0, s, X, (const float*)Wt, Vpart, T, F, M, K, g.tc);
     return launch_dominant(cov_half16_kernel<8, false>, grid, block, 0, s, X, (const float*)Wt, Vpart, T, F, M, K, g.tc);
+}
+
+// float64 sums (the `precise` arithmetic): 4 or 8 sources per pass.  Wt: scratch of (T + 1) x 16 doubles.
+// (one or two sources stay on the fp64 matrix-core kernel: a two-source instantiation of this one measured 523-590 us against
+//  474 at 2048 bins x 4000 frames x 16 channels -- the 34 conversion and product instructions per lane and frame are then
+//  two thirds of the work; three or four sources: 692 against 836 us, five to eight 1.06 against 1.57 ms, sixteen 2.08 against 3.10)
+bool cov_half16_f64_supported(int M, int K) { return M >= 10 && M <= 16 && M % 2 == 0 && K >= 3 && K <= 16; }
+int cov_half16_f64_sources_per_pass(int K) { return K <= 4 ? 4 : 8; }
+
+hipError_t launch_cov_half16_f64(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
+                                 double* Vpart, int T, int F, int M, int K, const CovGeom& g) {
+    if (!cov_half16_f64_supported(M, K) || R == nullptr || Wt == nullptr || g.tc % (4 * kH16Frames) != 0) return hipErrorInvalidValue;
+    double* wt = reinterpret_cast<double*>(Wt);
+    h64_weights_kernel<<<dim3(((T + 1) * kH64WeightStride + kBlock - 1) / kBlock), dim3(kBlock), 0, s>>>(R, wt, wscale, model, raw, T, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int ns = cov_half16_f64_sources_per_pass(K);
+    const dim3 grid((F + 1) / 2, g.nsplit, (K + ns - 1) / ns);
+    if (ns == 4) return launch_dominant(cov_half16f64_kernel<4>, grid, dim3(kBlock), 0, s, X, (const double*)wt, Vpart, T, F, M, K, g.tc);
+    return launch_dominant(cov_half16f64_kernel<8>, grid, dim3(kBlock), 0, s, X, (const double*)wt, Vpart, T, F, M, K, g.tc);
 }
 
 }  // namespace oiva

@@ -67,7 +67,7 @@ struct CovGeom {
     int tc;       // frames per split (multiple of 16)
     int kc;       // sources per pass (template KC)
     int nbg;      // bin groups of 16 (grid.x)
-    int half16 = 0; // 10/12/14/16 channels, 5..16 sources, float32: kernels_cov_half16.hip (2 bins per workgroup, all sources per pass)
+    int half16 = 0; // 10/12/14/16 channels, 5..16 sources: kernels_cov_half16.hip (2 bins per workgroup; float32: 5..16 sources, all per pass; float64: 3..16 sources, 4 or 8 per pass)
     int pair32 = 0; // 8 channels, >= 3 sources, float32: kernels_cov_pair32.hip (32 bins per workgroup, four sources per pass)
     int quad = 0; // 10/12/14/16 channels, few sources, float32: the vector-ALU kernel of kernels_cov_quad.hip (float64 partials)
 };
@@ -124,6 +124,11 @@ bool cov_half16_supported(int M, int K);
 int cov_half16_sources_per_pass(int K);
 hipError_t launch_cov_half16(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                              double* Vpart, int T, int F, int M, int K, const CovGeom& g);
+// the same decomposition with float64 sums (the `precise` arithmetic), 3..16 sources, 4 or 8 per pass; Wt: (T + 1, 16) DOUBLES
+bool cov_half16_f64_supported(int M, int K);
+int cov_half16_f64_sources_per_pass(int K);
+hipError_t launch_cov_half16_f64(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
+                                 double* Vpart, int T, int F, int M, int K, const CovGeom& g);
 int cov_sources_per_pass(int M, int K, bool f64);
 hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n);
 bool cov_supported(int M);

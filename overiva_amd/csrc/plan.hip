@@ -183,13 +183,18 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     }
     // many sources (5..16): the Hermitian half over 32 lanes per (bin, frame), every source in one pass; a wave's float32
     // chain is T / (4 nsplit) frames: <= 256 in `fast`, <= 128 with the float64 per-bin algebra behind it
-    if (p->M > 8 && !p->cov_f64() && p->cov_quad_on && p->K > 4 && cov_half16_supported(p->M, p->K)) {
+    // (float64 sums, `precise`, 3..16 sources: the same lanes with four or eight sources per pass; splits only to fill the chip)
+    if (p->M > 8 && p->cov_quad_on &&
+        (p->cov_f64() ? cov_half16_f64_supported(p->M, p->K) : p->K > 4 && cov_half16_supported(p->M, p->K))) {
         g.half16 = 1;
         g.nbg = ceil_div(p->F, 2);
-        g.kc = cov_half16_sources_per_pass(p->K);
+        g.kc = p->cov_f64() ? cov_half16_f64_sources_per_pass(p->K) : cov_half16_sources_per_pass(p->K);
         if (nsplit <= 0) {
-            nsplit = ceil_div(p->T, p->upd_f64() ? 512 : 1024);
-            while (g.nbg * nsplit < 2 * p->n_cu && ceil_div(p->T, nsplit + 1) >= 64) ++nsplit;
+            // (float64: no chain to bound; the four-source form runs a little faster in two rounds of workgroups -- 2048 x 4000
+            //  x 16 / 4: 1 split 744 us, 2 splits 691, 4 splits 693; the eight-source form does not care)
+            nsplit = p->cov_f64() ? (g.kc == 4 && p->T >= 1024 ? 2 : 1) : ceil_div(p->T, p->upd_f64() ? 512 : 1024);
+            const int per_cu = p->cov_f64() && g.kc == 4 ? 4 : 2;      // workgroups a CU holds (launch bounds of the kernels)
+            while (g.nbg * ceil_div(p->K, g.kc) * nsplit < per_cu * p->n_cu && ceil_div(p->T, nsplit + 1) >= 64) ++nsplit;
         }
         g.tc = round_up(ceil_div(p->T, nsplit), 16);
         g.nsplit = ceil_div(p->T, g.tc);
@@ -611,7 +616,7 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     alloc((void**)&p->Cx, nFMM * sizeof(double));
     alloc((void**)&p->Ppart, (size_t)p->pw.nb * nTK * sizeof(float));
     p->ppart_alloc = p->pw.nb;
-    alloc((void**)&p->Plocal, std::max(nTK, ((size_t)T + 1) * 16) * sizeof(float));   // also the (T + 1, 16) weights scratch
+    alloc((void**)&p->Plocal, std::max(nTK, ((size_t)T + 1) * 32) * sizeof(float));   // also the (T + 1, 16) weights scratch (floats or doubles)
     alloc((void**)&p->R, r_buffer_bytes(T, K));   // activations, zeroed pad rows, per-block sums (rsum_offset_floats)
     if (e == hipSuccess) e = hipMemset(p->R, 0, r_buffer_bytes(T, K));
     alloc((void**)&p->wscale, (size_t)K * sizeof(float));

@@ -1,6 +1,6 @@
 """The vector-ALU covariance kernels of 10 / 12 / 14 / 16-channel plans (reference overiva.py:179 and :87): four lanes per
 (bin, frame) for up to 4 sources (csrc/kernels_cov_quad.hip), 32 lanes per (bin, frame) and every source in one pass for
-5..16 (csrc/kernels_cov_half16.hip) -- against the oracle on ragged shapes, against the matrix-core kernel they replace,
+5..16 (csrc/kernels_cov_half16.hip, float32 and float64 sums) -- against the oracle on ragged shapes, against the matrix-core kernel they replace,
 the rules that select them, the default arithmetic of these shapes, and the full-size geometry (2048 bins x 4000 frames x
 16 channels / 2 sources; BASELINE configs[4] is tests/test_gpu_parity.py::test_cfg5_full_size_properties) through invariants
 that need no oracle."""
@@ -82,10 +82,43 @@ def test_many_source_covariances_against_oracle(oa, shape, splits):
     assert np.array_equal(V, np.conj(np.swapaxes(V, -1, -2)))
 
 
+@pytest.mark.parametrize("splits", [0, 1, 3])
+@pytest.mark.parametrize("shape", MANY + SHAPES, ids=lambda s: "x".join(str(v) for v in s[:4]))
+def test_covariances_in_float64_against_oracle(oa, shape, splits):
+    """`precise` with 3..16 sources: the lanes of the many-source kernel, float64 sums of exact products, 4 or 8 sources per
+    pass (source counts below, at and above one and two passes); Cx and one or two sources stay on the matrix-core kernel"""
+    T, F, M, K, _ = shape
+    if K < 3:
+        pytest.skip("one or two sources: the matrix-core kernel")
+    X = orc.synth_mixture(T, F, M, K, seed=4)
+    rinv = np.random.default_rng(5).gamma(2.0, 1.0, (T, K)).astype(np.float32)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision("precise")
+        assert p.set_cov_quad(True)
+        if splits:
+            p.set_cov_splits(min(splits, max(1, T // 16)))
+        p.set_x(X)
+        p.covariance()
+        Cx = p.get_cx()
+        p.t_set_rinv(rinv)
+        p.t_run_weighted_cov()
+        V = p.t_get_v(np.complex128)
+        p.set_cov_quad(False)
+        p.t_run_weighted_cov()
+        Vm = p.t_get_v(np.complex128)
+    eC = orc.rel_err(Cx, orc.input_covariance(X.astype(np.complex128)))
+    w = 1.0 / (np.float32(1) / rinv).astype(np.float64)      # the hook stores r = 1 / rinv in float32; the weight is 1 / r in float64
+    eV = orc.rel_err(V, orc.weighted_cov_all(X, w))
+    eM = orc.rel_err(V, Vm)                                    # (the matrix-core kernel takes its weights in float32)
+    print(f"\n[half16 f64] {shape[:4]} splits={splits}: V {eV:.1e} Cx {eC:.1e} vs matrix-core {eM:.1e}")
+    assert eV < 1e-12 and eC < 1e-12 and eM < 1e-7
+    assert np.array_equal(V, np.conj(np.swapaxes(V, -1, -2)))
+
+
 def test_selection_rules(oa):
     """one or two sources: every float32 mode; three or four: only with the float64 per-bin algebra (the matrix-core kernel is
-    faster in `fast`); five and more: the 32-lanes-per-(bin, frame) kernel in every float32 mode; never in `precise`, never for
-    odd channel counts; the switch turns both off"""
+    faster in `fast`); five and more: the 32-lanes-per-(bin, frame) kernel; `precise`: the float64 form of that kernel for
+    three and more sources; never for odd channel counts; the switch turns all of them off"""
     def active(M, K, mode, on=True):
         with oa.Plan(64, 20, M, K, "laplace") as p:
             p.set_precision(mode)
@@ -94,8 +127,10 @@ def test_selection_rules(oa):
     assert active(16, 2, "fast") and active(10, 1, "fast") and active(14, 2, "mixed")
     assert active(12, 3, "mixed") and active(16, 4, "mixed")
     assert not active(12, 3, "fast") and not active(16, 4, "fast")
-    assert not active(16, 2, "precise") and not active(11, 2, "fast") and not active(8, 2, "fast")
+    assert not active(11, 2, "fast") and not active(8, 2, "fast") and not active(13, 4, "precise")
     assert active(16, 5, "mixed") and active(16, 16, "fast") and active(12, 12, "mixed")      # many sources: kernels_cov_half16.hip
+    assert active(16, 5, "precise") and active(16, 16, "precise") and active(10, 3, "precise") and active(12, 4, "precise")
+    assert not active(15, 9, "precise") and not active(16, 2, "precise") and not active(16, 1, "precise")
     assert not active(16, 2, "fast", on=False)
     # the precision set AFTER the switch decides as well
     with oa.Plan(64, 20, 12, 3, "laplace") as p:
@@ -104,7 +139,7 @@ def test_selection_rules(oa):
         p.set_precision("mixed")
         assert p.set_cov_quad(True)
         p.set_precision("precise")
-        assert not p.set_cov_quad(True)
+        assert p.set_cov_quad(True)             # (the float64 form of the many-source kernel)
 
 
 @pytest.mark.parametrize("shape", [(163, 19, 16, 2), (150, 18, 10, 2), (141, 33, 14, 1), (128, 9, 16, 16), (120, 12, 12, 7)],
