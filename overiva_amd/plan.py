@@ -209,9 +209,9 @@ class Plan:
         _lib.check(self.lib.oiva_plan_set_cov_splits(self.h, int(n)))
 
     def set_cov_quad(self, enable=True):
-        """float32 covariance pass of a 10/12/14/16-channel plan: the vector-ALU kernels (default; four lanes per (bin, frame)
-        for <= 4 sources, 32 lanes and all sources in one pass for more) or the planar matrix-core kernel; returns whether
-        a vector-ALU kernel is now active"""
+        """covariance pass of a 10/12/14/16-channel plan: the vector-ALU kernels (default; float32 products: four lanes per
+        (bin, frame) for <= 4 sources, 32 lanes and all sources in one pass for more; ``precise``: the float64 form of the
+        latter for >= 3 sources) or the planar matrix-core kernel; returns whether a vector-ALU kernel is now active"""
         a = C.c_int()
         _lib.check(self.lib.oiva_plan_set_cov_quad(self.h, 1 if enable else 0, C.byref(a)))
         return bool(a.value)
