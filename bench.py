@@ -64,7 +64,7 @@ MODES = ("fast", "mixed", "precise")
 MODE_TEXT = {
     "fast": "fast (float32 products, lane chains and per-bin algebra; float64 sums across lanes and frame splits)",
     "mixed": "mixed (float32 products and lane chains of the covariance pass, float64 sums across lanes / splits, float64 per-bin "
-             "algebra with W_hat in complex128: what overiva() runs for complex64 input on <= 8 and on 10/12/14/16 channels)",
+             "algebra with W_hat in complex128: what overiva() runs for complex64 input)",
     "precise": "precise (covariance as float64 sums of exact float64 products + float64 per-bin algebra: what overiva() runs "
                "for complex128 input and for 9/11/13/15 channels)",
 }
@@ -227,7 +227,8 @@ def _cov_roofline(shape, mode, cov_ms):
         if kname.startswith(("cov_pair64", "cov_pair32")):
             roof["note"] = "avg_launch_ms is the event-bracketed stage: the weights pre-pass (~4 us) + the kernel + the gaps of the bracketing events"
         return kname, roof
-    if m % 2 == 0 and mode != "precise" and (k <= 2 or (k <= 4 and mode == "mixed")):
+    # (9 / 11 / 13 / 15 channels: the kernels of the next even count on a zero-padded copy of X; bytes stay the algorithmic ones)
+    if mode != "precise" and (k <= 2 or (k <= 4 and mode == "mixed")):
         # the Hermitian half on the vector ALU, four lanes per (bin, frame): one pass over X per two sources
         bytes_cov = cov_algorithmic_bytes(t, f, m, k) + (-(-k // 2) - 1) * 8 * t * f * m
         achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
@@ -236,7 +237,7 @@ def _cov_roofline(shape, mode, cov_ms):
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
                        "note": "co-limited by the vector ALU: 512 real FMAs per (bin, frame, source pair) at 16 channels against 128 at 8"}
-    if m % 2 == 0 and mode != "precise" and k > 4:
+    if mode != "precise" and k > 4:
         # the Hermitian half on the vector ALU, 32 lanes per (bin, frame), every source in one pass: bound by the packed-fp32
         # issue rate (2 + k instructions per complex entry slot, 160 slots per (bin, frame)), not by memory
         bytes_cov = cov_algorithmic_bytes(t, f, m, k)
@@ -251,7 +252,7 @@ def _cov_roofline(shape, mode, cov_ms):
                        "vector_alu": {"packed_wave_instructions_per_launch": instr, "issue_floor_ms": floor_ms, "frac_of_issue_floor": floor_ms / cov_ms},
                        "note": "NOT memory-bound: the vector ALU's packed-fp32 issue rate bounds it (vector_alu); the fp32 matrix cores "
                                "have the same peak and the planar form needs 2.8x the multiply-adds (it measured 1.69 ms at 16 x 16)"}
-    if m % 2 == 0 and mode == "precise" and k >= 3:
+    if mode == "precise" and k >= 3:
         # the same lanes with float64 sums of exact products, four or eight sources per pass: bound by the float64 issue rate of
         # the vector ALU (14 conversions + 20 + 10 * sources float64 instructions per lane and frame)
         ns = 4 if k <= 4 else 8
@@ -721,8 +722,8 @@ def main():
                     help="headline: BASELINE.json configs[2] (the metric's workload); cfg5: configs[4], 16 mics / 16 sources; "
                          "cfg2: configs[1]; shard8: one rank's shard of configs[3]; m16k2: 16 mics / 2 sources; tiny: test-only")
     ap.add_argument("--precision", choices=list(MODES), default=None,
-                    help="arithmetic of the timed run (default: what overiva() runs on this input -- mixed up to 8 channels and for "
-                         "10/12/14/16 channels, precise otherwise); the other modes are timed too")
+                    help="arithmetic of the timed run (default: mixed, what overiva() runs on complex64 input); the other modes "
+                         "are timed too")
     ap.add_argument("--cfg5-precision", choices=list(MODES), default="mixed",
                     help="arithmetic of the configs[4] entry of the N = 1 line (default: what overiva() runs on it)")
     ap.add_argument("--no-other-mode", action="store_true", help="do not also time the other arithmetic modes")
@@ -742,7 +743,7 @@ def main():
     args = ap.parse_args()
     select_config(args.config)
     if args.precision is None:
-        args.precision = "mixed" if M <= 8 or M % 2 == 0 else "precise"      # overiva_amd.overiva.resolve_precision
+        args.precision = "mixed"      # overiva_amd.overiva.resolve_precision for complex64 input
     world_env = int(os.environ.get("WORLD_SIZE", "0") or 0)
     if args.gpus > 1 and world_env == 0:
         # no launcher around us: be one.  Nothing above touched a GPU (no torch import, no HIP call).

@@ -202,12 +202,13 @@ int oiva_plan_iterate_timed(oiva_plan *p, int n, float *total_ms, float *per_ker
  * get/set the number of frame splits (0 = library default). */
 int oiva_plan_get_cov_splits(oiva_plan *p, int *nsplit);
 int oiva_plan_set_cov_splits(oiva_plan *p, int nsplit);
-/* Which kernel takes the covariance pass of a 10-, 12-, 14- or 16-channel plan: 1 (default) = the vector-ALU kernels
+/* Which kernel takes the covariance pass of a 9..16-channel plan: 1 (default) = the vector-ALU kernels
  * that form the Hermitian half and write float64 partial sums -- float32 products: four lanes per (bin, frame) for up to 4
  * sources (csrc/kernels_cov_quad.hip; 3 and 4 sources only with the float64 per-bin algebra), 32 lanes per (bin, frame) and
  * every source in one pass for 5..16 (csrc/kernels_cov_half16.hip); OIVA_PREC_COV_F64: the float64 form of the latter for
- * 3..16 sources -- 0 = the planar matrix-core kernel, which odd channel counts (and OIVA_PREC_COV_F64 with one or two
- * sources) always use.  *active (may be NULL) receives whether a vector-ALU kernel is what this plan now launches.  Drops captured
+ * 3..16 sources; a plan with 9, 11, 13 or 15 channels runs them on its own copy of X padded by one zero channel per bin
+ * ((M + 1) / M of X more device memory, filled by oiva_plan_covariance) -- 0 = the planar matrix-core kernel, which
+ * OIVA_PREC_COV_F64 with one or two sources always uses.  *active (may be NULL) receives whether a vector-ALU kernel is what this plan now launches.  Drops captured
  * graphs. */
 int oiva_plan_set_cov_quad(oiva_plan *p, int enable, int *active);
 /* same for the demix+power pass (0 = library default) */

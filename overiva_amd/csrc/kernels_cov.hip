@@ -389,12 +389,30 @@ int cov_sources_per_pass(int M, int K, bool f64) {
     return kc;
 }
 
-hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
+// one zero channel behind every (frame, bin)'s M: the even channel pitch the vector-ALU kernels of 10..16 channels read
+__global__ __launch_bounds__(kBlock) void pad_channels_kernel(const float2* __restrict__ X, float2* __restrict__ Xpad, long long n, int M) {
+    const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;          // element of the padded tensor
+    if (e >= n) return;
+    const long long tf = e / (M + 1);
+    const int c = (int)(e - tf * (M + 1));
+    Xpad[e] = c < M ? X[tf * M + c] : make_float2(0.f, 0.f);
+}
+
+hipError_t launch_pad_channels(hipStream_t s, const float2* X, float2* Xpad, long long n_tf, int M) {
+    const long long n = n_tf * (M + 1);
+    pad_channels_kernel<<<dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s>>>(X, Xpad, n, M);
+    return hipGetLastError();
+}
+
+hipError_t launch_cov(hipStream_t s, const float2* X, const float2* Xpad, const float* R, float* Wt, float* wscale, int model, int raw,
                       void* Vpart, bool f64, int T, int F, int M, int K, const CovGeom& g) {
-    if (M > 8 && g.half16 && !f64) return launch_cov_half16(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
+    if (g.pad && Xpad == nullptr) return hipErrorInvalidValue;
+    const float2* Xv = g.pad ? Xpad : X;        // what the vector-ALU kernels of 10..16 channels read, at a pitch of Mp channels
+    const int Mp = g.pad ? M + 1 : M;
+    if (M > 8 && g.half16 && !f64) return launch_cov_half16(s, Xv, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, Mp, M, K, g);
     if (M > 8 && g.half16 && f64 && R != nullptr)
-        return launch_cov_half16_f64(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
-    if (M > 8 && g.quad && !f64) return launch_cov_quad(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
+        return launch_cov_half16_f64(s, Xv, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, Mp, M, K, g);
+    if (M > 8 && g.quad && !f64) return launch_cov_quad(s, Xv, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, Mp, M, K, g);
     if (M > 8) return launch_cov_mfma(s, X, R, Wt, wscale, model, raw, Vpart, f64, T, F, M, K, g.nsplit, g.tc);
     if (!f64 && g.pair32) return launch_cov_pair32(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);
     if (f64 && cov_pair64_supported(M)) return launch_cov_pair64(s, X, R, Wt, wscale, model, raw, static_cast<double*>(Vpart), T, F, M, K, g);

@@ -117,7 +117,7 @@ __device__ __forceinline__ void h16_frame(v2f (&acc)[2 * NP][kH16Entries], const
 // NP: source PAIRS per pass (8: up to 16 sources, 6: up to 12, 4: up to 8, 1: the unit-weight pass)
 template <int NP, bool UNIT>
 __global__ __launch_bounds__(kBlock, 2) void cov_half16_kernel(const float2* __restrict__ X, const float* __restrict__ Wt,
-                                                               double* __restrict__ Vpart, int T, int F, int M, int K, int tc) {
+                                                               double* __restrict__ Vpart, int T, int F, int M, int Mv, int K, int tc) {
     constexpr int kRingBytes = kWaves * kH16Stages * kH16Stage;
     constexpr int kScratchBytes = (int)sizeof(float) * kH16Chunk * kH16LdsStride;
     __shared__ float4 ring[(kRingBytes > kScratchBytes ? kRingBytes : kScratchBytes) / 16 + 1];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_half16_kernel(const float2* __r
     //      (frame split, bin, source).  accumulator n = source * 10 + entry * 2 + (re | im)
     float* lds = reinterpret_cast<float*>(ring);
     constexpr int NACC = 2 * NP * kH16Entries * 2;
-    const int NA = M * M;
+    const int NA = Mv * Mv;            // Mv <= M: the matrix that is stored (M: channel pitch of X)
     // thread tid sums accumulator wave + 4 v (+ r0) of LANE `lane` in every round: the packed positions of that lane's five
     // entries are computed once (-1: dropped -- below the diagonal of a diagonal block, or a channel >= M)
     int pos[kH16Entries];
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_half16_kernel(const float2* __r
         int ci, di;
         h16_entry(e, ent, &ci, &di);
         offdiag[ent] = ci < di;
-        pos[ent] = (di < M && ci <= di) ? (ci == di ? ci : herm_pair_index(M, ci, di)) : -1;
+        pos[ent] = (di < Mv && ci <= di) ? (ci == di ? ci : herm_pair_index(Mv, ci, di)) : -1;
     }
     const int fo = f0 + h;
     double* const vb = Vpart + (((size_t)blockIdx.y * F + (fo < F ? fo : F - 1)) * K + k0) * NA;
@@ -308,7 +308,7 @@ __device__ __forceinline__ void h64_frame(double (&accr)[NS][kH16Entries], doubl
 
 template <int NS>
 __global__ __launch_bounds__(kBlock, NS == 8 ? 2 : 4) void cov_half16f64_kernel(const float2* __restrict__ X, const double* __restrict__ Wt,
-                                                                  double* __restrict__ Vpart, int T, int F, int M, int K, int tc) {
+                                                                  double* __restrict__ Vpart, int T, int F, int M, int Mv, int K, int tc) {
     constexpr int kRingBytes = kWaves * kH16Stages * kH16Stage;
     constexpr int kScratchBytes = (int)sizeof(double) * kH64Chunk * kH16LdsStride;
     __shared__ float4 ring[(kRingBytes > kScratchBytes ? kRingBytes : kScratchBytes) / 16 + 1];
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kBlock, NS == 8 ? 2 : 4) void cov_half16f64_kernel(
     // the four waves added in fixed order, rounds of 8 doubles; accumulator n = source * 10 + entry * 2 + (re | im)
     double* lds = reinterpret_cast<double*>(ring);
     constexpr int NACC = NS * kH16Entries * 2;
-    const int NA = M * M;
+    const int NA = Mv * Mv;            // Mv <= M: the matrix that is stored (M: channel pitch of X)
     int pos[kH16Entries];
     bool offdiag[kH16Entries];
 #pragma unroll
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kBlock, NS == 8 ? 2 : 4) void cov_half16f64_kernel(
         int ci, di;
         h16_entry(e, ent, &ci, &di);
         offdiag[ent] = ci < di;
-        pos[ent] = (di < M && ci <= di) ? (ci == di ? ci : herm_pair_index(M, ci, di)) : -1;
+        pos[ent] = (di < Mv && ci <= di) ? (ci == di ? ci : herm_pair_index(Mv, ci, di)) : -1;
     }
     const int fo = f0 + h;
     double* const vb = Vpart + (((size_t)blockIdx.y * F + (fo < F ? fo : F - 1)) * K + k0) * NA;
@@ -435,22 +435,22 @@ int cov_half16_sources_per_pass(int K) { return K <= 8 ? 8 : (K <= 12 ? 12 : 16)
 
 // Wt: (T + 1, 16) scratch for the final weights (row T zeroed here); R == nullptr: unit weights (K = 1)
 hipError_t launch_cov_half16(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
-                             double* Vpart, int T, int F, int M, int K, const CovGeom& g) {
-    if (!cov_half16_supported(M, K) || g.tc % (4 * kH16Frames) != 0) return hipErrorInvalidValue;
+                             double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g) {
+    if (!cov_half16_supported(M, K) || Mv > M || Mv < M - 1 || g.tc % (4 * kH16Frames) != 0) return hipErrorInvalidValue;
     const dim3 grid((F + 1) / 2, g.nsplit, 1), block(kBlock);
     if (R == nullptr) {
         if (K != 1) return hipErrorInvalidValue;
-        return launch_dominant(cov_half16_kernel<1, true>, grid, block, 0, s, X, (const float*)nullptr, Vpart, T, F, M, K, g.tc);
+        return launch_dominant(cov_half16_kernel<1, true>, grid, block, 0, s, X, (const float*)nullptr, Vpart, T, F, M, Mv, K, g.tc);
     }
     if (Wt == nullptr) return hipErrorInvalidValue;
     hipError_t e = launch_cov_weights(s, R, Wt, wscale, model, raw, T, K, kH16WeightStride);
     if (e == hipSuccess) e = hipMemsetAsync(Wt + (size_t)T * kH16WeightStride, 0, kH16WeightStride * sizeof(float), s);
     if (e != hipSuccess) return e;
     if (K <= 8)
-        return launch_dominant(cov_half16_kernel<4, false>, grid, block, 0, s, X, (const float*)Wt, Vpart, T, F, M, K, g.tc);
+        return launch_dominant(cov_half16_kernel<4, false>, grid, block, 0, s, X, (const float*)Wt, Vpart, T, F, M, Mv, K, g.tc);
     if (K <= 12)
-        return launch_dominant(cov_half16_kernel<6, false>, grid, block, 0, s, X, (const float*)Wt, Vpart, T, F, M, K, g.tc);
-    return launch_dominant(cov_half16_kernel<8, false>, grid, block, 0, s, X, (const float*)Wt, Vpart, T, F, M, K, g.tc);
+        return launch_dominant(cov_half16_kernel<6, false>, grid, block, 0, s, X, (const float*)Wt, Vpart, T, F, M, Mv, K, g.tc);
+    return launch_dominant(cov_half16_kernel<8, false>, grid, block, 0, s, X, (const float*)Wt, Vpart, T, F, M, Mv, K, g.tc);
 }
 
 // float64 sums (the `precise` arithmetic): 4 or 8 sources per pass.  Wt: scratch of (T + 1) x 16 doubles.
@@ -461,16 +461,16 @@ bool cov_half16_f64_supported(int M, int K) { return M >= 10 && M <= 16 && M % 2
 int cov_half16_f64_sources_per_pass(int K) { return K <= 4 ? 4 : 8; }
 
 hipError_t launch_cov_half16_f64(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
-                                 double* Vpart, int T, int F, int M, int K, const CovGeom& g) {
-    if (!cov_half16_f64_supported(M, K) || R == nullptr || Wt == nullptr || g.tc % (4 * kH16Frames) != 0) return hipErrorInvalidValue;
+                                 double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g) {
+    if (!cov_half16_f64_supported(M, K) || Mv > M || Mv < M - 1 || R == nullptr || Wt == nullptr || g.tc % (4 * kH16Frames) != 0) return hipErrorInvalidValue;
     double* wt = reinterpret_cast<double*>(Wt);
     h64_weights_kernel<<<dim3(((T + 1) * kH64WeightStride + kBlock - 1) / kBlock), dim3(kBlock), 0, s>>>(R, wt, wscale, model, raw, T, K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int ns = cov_half16_f64_sources_per_pass(K);
     const dim3 grid((F + 1) / 2, g.nsplit, (K + ns - 1) / ns);
-    if (ns == 4) return launch_dominant(cov_half16f64_kernel<4>, grid, dim3(kBlock), 0, s, X, (const double*)wt, Vpart, T, F, M, K, g.tc);
-    return launch_dominant(cov_half16f64_kernel<8>, grid, dim3(kBlock), 0, s, X, (const double*)wt, Vpart, T, F, M, K, g.tc);
+    if (ns == 4) return launch_dominant(cov_half16f64_kernel<4>, grid, dim3(kBlock), 0, s, X, (const double*)wt, Vpart, T, F, M, Mv, K, g.tc);
+    return launch_dominant(cov_half16f64_kernel<8>, grid, dim3(kBlock), 0, s, X, (const double*)wt, Vpart, T, F, M, Mv, K, g.tc);
 }
 
 }  // namespace oiva

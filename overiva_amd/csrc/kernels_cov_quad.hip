@@ -190,7 +190,7 @@ __device__ __forceinline__ int quad_position(int j, int a, int M, bool* neg) {
 
 template <int KC, bool UNIT>
 __global__ __launch_bounds__(kBlock, 2) void cov_quad_kernel(const float2* __restrict__ X, const float* __restrict__ Wt,
-                                                             double* __restrict__ Vpart, int T, int F, int M, int K, int tc) {
+                                                             double* __restrict__ Vpart, int T, int F, int M, int Mv, int K, int tc) {
     __shared__ float4 ring[kWaves * kQuadStages * kQuadStage / 16];      // 64 KB: two workgroups per CU
     static_assert(sizeof(float4) * (kWaves * kQuadStages * kQuadStage / 16) >= sizeof(float) * kQuadChunk * kQuadLdsStride,
                   "reduction scratch aliases the ring");
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_quad_kernel(const float2* __res
     //      (frame split, bin, source)
     float* lds = reinterpret_cast<float*>(ring);
     constexpr int NACC = kQuadAcc * KC;
-    const int NA = M * M;
+    const int NA = Mv * Mv;            // Mv <= M: the matrix that is stored (M: channel pitch of X)
 #pragma unroll
     for (int r0 = 0; r0 < NACC; r0 += kQuadChunk) {
         __syncthreads();
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_quad_kernel(const float2* __res
             const int kk = e / kQuadAcc;            // constant per round (64 % 16 == 0)
             const int fo = f0 + (l >> 2);
             bool neg;
-            const int pos = quad_position(l & 3, e % kQuadAcc, M, &neg);
+            const int pos = quad_position(l & 3, e % kQuadAcc, Mv, &neg);
             if (pos >= 0 && fo < F && k0 + kk < K)
                 Vpart[(((size_t)blockIdx.y * F + fo) * K + k0 + kk) * NA + pos] = neg ? -s : s;
         }
@@ -341,26 +341,27 @@ __global__ __launch_bounds__(kBlock, 2) void cov_quad_kernel(const float2* __res
 
 }  // namespace
 
+// M: channel pitch of X (even); Mv <= M: channels of the matrices (an odd channel count runs on a copy of X padded by one zero channel)
 bool cov_quad_supported(int M, int K) { return M >= 10 && M <= 16 && M % 2 == 0 && K >= 1 && K <= 4; }
 
 int cov_quad_sources_per_pass(int K) { return K >= 2 ? 2 : 1; }
 
 hipError_t launch_cov_quad(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
-                           double* Vpart, int T, int F, int M, int K, const CovGeom& g) {
-    if (!cov_quad_supported(M, K) || g.tc % (4 * kQuadFrames) != 0) return hipErrorInvalidValue;
+                           double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g) {
+    if (!cov_quad_supported(M, K) || Mv > M || Mv < M - 1 || g.tc % (4 * kQuadFrames) != 0) return hipErrorInvalidValue;
     if (R == nullptr) {
         if (K != 1) return hipErrorInvalidValue;
         return launch_dominant(cov_quad_kernel<1, true>, dim3(g.nbg, g.nsplit, 1), dim3(kBlock), 0, s, X, (const float*)nullptr, Vpart,
-                               T, F, M, K, g.tc);
+                               T, F, M, Mv, K, g.tc);
     }
     if (Wt == nullptr) return hipErrorInvalidValue;
     hipError_t e = launch_cov_weights(s, R, Wt, wscale, model, raw, T, K, kQuadWeightStride);
     if (e != hipSuccess) return e;
     if (g.kc == 2)
         return launch_dominant(cov_quad_kernel<2, false>, dim3(g.nbg, g.nsplit, (K + 1) / 2), dim3(kBlock), 0, s, X, (const float*)Wt,
-                               Vpart, T, F, M, K, g.tc);
+                               Vpart, T, F, M, Mv, K, g.tc);
     return launch_dominant(cov_quad_kernel<1, false>, dim3(g.nbg, g.nsplit, K), dim3(kBlock), 0, s, X, (const float*)Wt, Vpart, T, F,
-                           M, K, g.tc);
+                           M, Mv, K, g.tc);
 }
 
 }  // namespace oiva

@@ -69,6 +69,7 @@ struct CovGeom {
     int nbg;      // bin groups of 16 (grid.x)
     int half16 = 0; // 10/12/14/16 channels, 5..16 sources: kernels_cov_half16.hip (2 bins per workgroup; float32: 5..16 sources, all per pass; float64: 3..16 sources, 4 or 8 per pass)
     int pair32 = 0; // 8 channels, >= 3 sources, float32: kernels_cov_pair32.hip (32 bins per workgroup, four sources per pass)
+    int pad = 0;  // odd channel count on the vector-ALU kernels: they read the copy of X padded to M + 1 channels
     int quad = 0; // 10/12/14/16 channels, few sources, float32: the vector-ALU kernel of kernels_cov_quad.hip (float64 partials)
 };
 struct PowGeom {
@@ -86,8 +87,11 @@ constexpr int kPowMaxFrames = 512;
 //   gamma is taken as 1.  wscale (K): out, gamma (laplace) | sqrt(gamma) (gauss), written by one workgroup.
 //   Vpart [nsplit][F][K][M*M] packed partial sums (NOT divided by T), float32 or (f64 != 0) float64
 //   f64: accumulate in float64 (the reference's arithmetic: its float64 r_inv promotes overiva.py:179 to complex128)
-hipError_t launch_cov(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
+// Xpad: (T, F, M + 1) copy of X with one zero channel behind every bin's M (odd 9..15 channels; launch_pad_channels), read by
+// the vector-ALU kernels when g.pad is set; else nullptr
+hipError_t launch_cov(hipStream_t s, const float2* X, const float2* Xpad, const float* R, float* Wt, float* wscale, int model, int raw,
                       void* Vpart, bool f64, int T, int F, int M, int K, const CovGeom& g);
+hipError_t launch_pad_channels(hipStream_t s, const float2* X, float2* Xpad, long long n_tf, int M);
 // planar matrix-core kernel for 9..16 channels (grid = F bins x nsplit, tc frames per split, tc multiple of 4)
 //   Wt (T,16): scratch for the final weights (written by a small pre-pass)
 hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
@@ -98,7 +102,7 @@ hipError_t launch_cov_mfma(hipStream_t s, const float2* X, const float* R, float
 bool cov_quad_supported(int M, int K);
 int cov_quad_sources_per_pass(int K);
 hipError_t launch_cov_quad(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
-                           double* Vpart, int T, int F, int M, int K, const CovGeom& g);
+                           double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g);
 // pre-pass of the 9..16-channel kernels: Wt (T, Kp) = 1 / max(r / gamma, eps), columns >= K zero; writes wscale (K)
 hipError_t launch_cov_weights(hipStream_t s, const float* R, float* Wt, float* wscale, int model, int raw, int T, int K, int Kp);
 // float64 vector-ALU kernel for 8 channels (kernels_cov_pair64.hip): the Hermitian half split over two lanes per (bin, frame),
@@ -123,12 +127,12 @@ hipError_t launch_cov_pair32(hipStream_t s, const float2* X, const float* R, flo
 bool cov_half16_supported(int M, int K);
 int cov_half16_sources_per_pass(int K);
 hipError_t launch_cov_half16(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
-                             double* Vpart, int T, int F, int M, int K, const CovGeom& g);
+                             double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g);
 // the same decomposition with float64 sums (the `precise` arithmetic), 3..16 sources, 4 or 8 per pass; Wt: (T + 1, 16) DOUBLES
 bool cov_half16_f64_supported(int M, int K);
 int cov_half16_f64_sources_per_pass(int K);
 hipError_t launch_cov_half16_f64(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
-                                 double* Vpart, int T, int F, int M, int K, const CovGeom& g);
+                                 double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g);
 int cov_sources_per_pass(int M, int K, bool f64);
 hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n);
 bool cov_supported(int M);

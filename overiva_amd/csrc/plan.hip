@@ -58,6 +58,7 @@ struct oiva_plan {
 
     const float2* X = nullptr;  // (T,F,M)
     float2* X_owned = nullptr;
+    float2* X_pad = nullptr;    // (T, F, M + 1): X with a zero channel behind every bin's M, for the vector-ALU covariance kernels at 9/11/13/15 channels
     float2* What = nullptr;     // (F,M,M) complex64: what the streaming kernels read
     double2* What64 = nullptr;  // (F,M,M) complex128: carried between iterations by the float64 update
     bool what64_valid = false;
@@ -81,6 +82,7 @@ struct oiva_plan {
     int vpart_splits_alloc = 0;
 
     bool have_x = false, have_cx = false, have_w = false;
+    bool pad_valid = false;       // X_pad holds the current X
     bool wscale_pending = false;  // wscale computed (by the covariance pass), update not yet applied
     int raw_weights = 0;          // test hook: R holds final 1/weights, no gamma normalisation
     int prec = 0;                 // OIVA_PREC_* bits (oiva_plan_set_precision)
@@ -160,7 +162,10 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     // form (measured 486-517 against 459 us at 2048 x 4000 x 16) but with float64 partial sums of short float32 chains,
     // which is what the float64 per-bin algebra of the `mixed` mode needs -- and 1.8 times faster than the float64
     // matrix-core pass that mode would otherwise have to be replaced by
-    if (p->M > 8 && !p->cov_f64() && p->cov_quad_on && cov_quad_supported(p->M, p->K) && (p->K <= 2 || p->upd_f64())) {
+    // (9, 11, 13, 15 channels: the same kernels on the copy of X padded by one zero channel, plan_covariance)
+    const int Mc = p->M + (p->M > 8 && p->M % 2 && p->X_pad != nullptr ? 1 : 0);
+    g.pad = Mc != p->M;
+    if (p->M > 8 && !p->cov_f64() && p->cov_quad_on && cov_quad_supported(Mc, p->K) && (p->K <= 2 || p->upd_f64())) {
         // one round of two workgroups per CU
         g.quad = 1;
         g.kc = cov_quad_sources_per_pass(p->K);
@@ -185,7 +190,7 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     // chain is T / (4 nsplit) frames: <= 256 in `fast`, <= 128 with the float64 per-bin algebra behind it
     // (float64 sums, `precise`, 3..16 sources: the same lanes with four or eight sources per pass; splits only to fill the chip)
     if (p->M > 8 && p->cov_quad_on &&
-        (p->cov_f64() ? cov_half16_f64_supported(p->M, p->K) : p->K > 4 && cov_half16_supported(p->M, p->K))) {
+        (p->cov_f64() ? cov_half16_f64_supported(Mc, p->K) : p->K > 4 && cov_half16_supported(Mc, p->K))) {
         g.half16 = 1;
         g.nbg = ceil_div(p->F, 2);
         g.kc = p->cov_f64() ? cov_half16_f64_sources_per_pass(p->K) : cov_half16_sources_per_pass(p->K);
@@ -322,7 +327,7 @@ int stage_activation(oiva_plan* p, const float* parts, int nparts) {
     return OIVA_OK;
 }
 int stage_cov(oiva_plan* p) {
-    HIP_TRY(launch_cov(p->stream, p->X, p->R, p->Plocal /* weights scratch, (T,16) */, p->wscale, p->model,
+    HIP_TRY(launch_cov(p->stream, p->X, p->X_pad, p->R, p->Plocal /* weights scratch, (T,16) */, p->wscale, p->model,
                        p->raw_weights, p->Vpart, p->cov_f64(), p->T, p->F, p->M, p->K, p->cov));
     p->wscale_pending = !p->raw_weights;
     return OIVA_OK;
@@ -529,6 +534,14 @@ int download_what(oiva_plan* p, std::vector<double2>& wh) {
     return OIVA_OK;
 }
 
+// the padded copy of X the vector-ALU covariance kernels read at 9 / 11 / 13 / 15 channels
+int ensure_pad(oiva_plan* p) {
+    if (p->X_pad == nullptr || p->pad_valid) return OIVA_OK;
+    HIP_TRY(launch_pad_channels(p->stream, p->X, p->X_pad, (long long)p->T * p->F, p->M));
+    p->pad_valid = true;
+    return OIVA_OK;
+}
+
 int check_ready(oiva_plan* p) {
     NEED(p != nullptr, OIVA_ERR_ARG, "null plan");
     NEED(p->have_x, OIVA_ERR_STATE, "X not set (oiva_plan_set_x_host/_dev)");
@@ -601,6 +614,15 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             p->n_cu = prop.multiProcessorCount;
     }
+    if (M > 8 && M % 2 == 1) {
+        // 9 / 11 / 13 / 15 channels: the vector-ALU covariance kernels read 16-byte pieces at an even channel pitch, so
+        // they get their own copy of X with one zero channel per bin (filled by oiva_plan_covariance; + (M + 1) / M of X)
+        hipError_t ep = hipMalloc((void**)&p->X_pad, (size_t)T * F * (M + 1) * sizeof(float2));
+        if (ep != hipSuccess) {
+            oiva_plan_destroy(p);
+            return fail(OIVA_ERR_HIP, std::string("allocation of the padded copy of X failed: ") + hipGetErrorString(ep));
+        }
+    }
     choose_cov_geom(p, 0);
     choose_pow_geom(p, 0);
     choose_stats_geom(p);
@@ -646,7 +668,7 @@ int oiva_plan_destroy(oiva_plan* p) {
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->graph_batch_exec) (void)hipGraphExecDestroy(p->graph_batch_exec);
     if (p->og_graph) (void)hipGraphExecDestroy(p->og_graph);
-    void* bufs[] = {p->X_owned, p->What, p->What64, p->Cx,        p->Vpart,    p->Ppart, p->Plocal, p->res_block, p->res_trace_buf,
+    void* bufs[] = {p->X_owned, p->X_pad, p->What, p->What64, p->Cx,        p->Vpart,    p->Ppart, p->Plocal, p->res_block, p->res_trace_buf,
                     p->R,       p->wscale, p->Spart, p->Y,      p->scratch_c, p->scratch_p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -675,6 +697,7 @@ int oiva_plan_set_x_host(oiva_plan* p, const void* X, long long row_pitch_bytes)
     p->X = p->X_owned;
     p->have_x = true;
     p->have_cx = false;
+    p->pad_valid = false;
     return OIVA_OK;
 }
 
@@ -708,6 +731,7 @@ int oiva_plan_set_x_host_c128(oiva_plan* p, const void* X, long long row_pitch_b
     p->X = p->X_owned;
     p->have_x = true;
     p->have_cx = false;
+    p->pad_valid = false;
     return OIVA_OK;
 }
 
@@ -723,6 +747,7 @@ int oiva_plan_set_x_dev(oiva_plan* p, const void* X_dev) {
     p->X = (const float2*)X_dev;
     p->have_x = true;
     p->have_cx = false;
+    p->pad_valid = false;
     return OIVA_OK;
 }
 
@@ -730,10 +755,15 @@ int oiva_plan_covariance(oiva_plan* p) {
     NEED(p, OIVA_ERR_ARG, "null plan");
     NEED(p->have_x, OIVA_ERR_STATE, "X not set");
     DeviceGuard guard(p->device);
+    // (the padded copy follows X here: every path that changes X clears have_cx, and the iteration needs Cx; a borrowed X
+    //  rewritten in place needs a new Cx too)
+    p->pad_valid = false;
+    int rcp = ensure_pad(p);
+    if (rcp) return rcp;
     CovGeom g = p->cov;
     g.kc = 1;
     // unit weights, one "source": partials land in Vpart laid out as [nsplit][F][1][M*M]
-    HIP_TRY(launch_cov(p->stream, p->X, nullptr, nullptr, nullptr, p->model, 0, p->Vpart, p->cov_f64(), p->T, p->F, p->M, 1, g));
+    HIP_TRY(launch_cov(p->stream, p->X, p->X_pad, nullptr, nullptr, nullptr, p->model, 0, p->Vpart, p->cov_f64(), p->T, p->F, p->M, 1, g));
     HIP_TRY(launch_sum_parts(p->stream, p->Vpart, p->vpart_f64(), g.nsplit, p->Cx, (long long)p->F * p->M * p->M, 1. / (double)p->T));
     p->have_cx = true;
     return OIVA_OK;
@@ -1283,7 +1313,7 @@ int oiva_plan_ogive_iterate(oiva_plan* p, int first_epoch, int n, double step_si
             int r = stage_power(p);                                                             // ive.py:196 + the norm of :210/:213
             if (r) return r;
             HIP_TRY(launch_activation(p->stream, p->Ppart, p->pw.nb, p->R, p->T, 1, amodel, p->F));   // ive.py:209-217 (floor + 1/r in the consumer)
-            HIP_TRY(launch_cov(p->stream, p->X, p->R, p->Plocal, p->wscale, p->model, /*raw: weights 1 / max(r, eps)*/ 1, p->Vpart,
+            HIP_TRY(launch_cov(p->stream, p->X, p->X_pad, p->R, p->Plocal, p->wscale, p->model, /*raw: weights 1 / max(r, eps)*/ 1, p->Vpart,
                                p->cov_f64(), p->T, p->F, p->M, 1, p->cov));                    // ive.py:221-227
             HIP_TRY(launch_ogive_step(p->stream, p->og, p->Vpart, p->vpart_f64(), p->cov.nsplit, p->T, p->F, p->M, step_size,
                                       tol));                                                     // ive.py:228-246
@@ -1371,6 +1401,8 @@ int oiva_test_run_weighted_cov(oiva_plan* p) {
     NEED(p, OIVA_ERR_ARG, "null plan");
     NEED(p->have_x, OIVA_ERR_STATE, "X not set");
     DeviceGuard guard(p->device);
+    int rc = ensure_pad(p);
+    if (rc) return rc;
     return stage_cov(p);
 }
 

@@ -6,8 +6,8 @@ the reference, which computes in the dtype of X (``overiva.py:89,126-131``): com
 weighted covariance as float64 sums of exact float64 products and the per-bin algebra in float64 with W_hat carried in
 complex128, i.e. the reference's complex128 arithmetic applied to complex64-rounded data; complex64 input runs ``"mixed"``
 -- float32 products and short float32 lane chains in the covariance pass, every longer sum and the per-bin algebra in
-float64: closer to the reference's complex128 result than the reference's own complex64 arithmetic is -- wherever the
-covariance kernel of the shape provides that (``resolve_precision``).  ``"fast"`` is float32 in the per-bin algebra too:
+float64: closer to the reference's complex128 result than the reference's own complex64 arithmetic is
+(``resolve_precision``).  ``"fast"`` is float32 in the per-bin algebra too:
 1e-5 on well-conditioned input, a few times the reference's complex64 noise otherwise
 (tests/test_gpu_parity.py::test_fast_mode_accuracy).
 
@@ -42,16 +42,16 @@ def set_precision(mode):
 
 def resolve_precision(dtype, n_chan, mode=None, n_src=None):
     """``"auto"`` follows the reference, which computes in the dtype of X (overiva.py:89,126,131): complex128 input ->
-    ``"precise"``; complex64 input -> ``"mixed"`` wherever the covariance pass hands float64 sums of short float32
-    chains to the float64 per-bin algebra: up to 8 channels and 10 / 12 / 14 / 16 channels (csrc/kernels_cov_quad.hip,
-    csrc/kernels_cov_half16.hip); 9, 11, 13 and 15 channels run the matrix-core pass, whose float32 form keeps float32
-    partial sums -> ``"precise"``.  (``n_src`` no longer matters; kept for callers.)"""
+    ``"precise"``; complex64 input -> ``"mixed"``: at every supported channel count the covariance pass hands float64 sums of
+    short float32 chains to the float64 per-bin algebra (up to 8 channels: csrc/kernels_cov.hip; 9..16:
+    csrc/kernels_cov_quad.hip, csrc/kernels_cov_half16.hip -- odd counts on a copy of X padded by one zero channel).
+    (``n_chan`` and ``n_src`` no longer matter; kept for callers.)"""
     mode = _precision if mode is None else mode
     if mode != "auto":
         return mode
     if np.dtype(dtype) != np.complex64:
         return "precise"
-    return "mixed" if n_chan <= 8 or (n_chan % 2 == 0 and n_chan <= 16) else "precise"
+    return "mixed"
 
 
 def get_precision():

