@@ -14,6 +14,36 @@ GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "needs(*keys): entries the golden fixture of this parametrisation must hold; `{model}`-style "
+                                       "fields are filled from the test's other parameters.  Parametrisations without them are "
+                                       "DESELECTED at collection (the F >= 64 fixtures store W only, for n_iter 1, 5, 20)")
+
+
+_KEYS = {}
+
+
+def _fixture_keys(path):
+    if path not in _KEYS:
+        with np.load(path) as d:
+            _KEYS[path] = set(d.files)
+    return _KEYS[path]
+
+
+def pytest_collection_modifyitems(config, items):
+    keep, drop = [], []
+    for it in items:
+        m = it.get_closest_marker("needs")
+        cs = getattr(it, "callspec", None)
+        if m is not None and cs is not None and "golden" in cs.params:
+            have = _fixture_keys(cs.params["golden"])
+            fields = {k: v for k, v in cs.params.items() if k != "golden"}
+            if any(k.format(**fields) not in have for k in m.args):
+                drop.append(it)
+                continue
+        keep.append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 def golden_files():
@@ -34,7 +64,7 @@ def golden(request):
 
 
 def need(g, *keys):
-    """skip when a fixture does not hold an entry (the F >= 64 fixtures store W only, for n_iter 1, 5, 20)"""
+    """skip when a fixture does not hold an entry (tests that cannot say so with @pytest.mark.needs)"""
     for k in keys:
         if k not in g:
             pytest.skip(f"fixture {g['_id']} has no {k}")

@@ -138,14 +138,13 @@ def test_demix_power(oa, golden):
     assert orc.rel_err(pw, ref) < TOL_KERNEL
 
 
+@pytest.mark.needs("im_{model}_e0_s0_V")
 @pytest.mark.parametrize("rows", [False, True], ids=["lane-per-element", "lane-per-row"])
 @pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
 @pytest.mark.parametrize("model", ["laplace", "gauss"])
 def test_ip_update(oa, golden, model, fp64, rows):
     """weighted covariance + per-bin chain (IP1 solve, normalisation, J) from the reference's own
     traced state at overiva.py:181 (W_hat after gamma scaling, r_inv) -> W_hat after the epoch."""
-    if f"im_{model}_e0_s0_V" not in golden:
-        pytest.skip("no traced intermediates in this fixture")
     X, K = golden["X"], int(golden["K"])
     T, F, M = X.shape
     for e in (0, 1):
@@ -205,12 +204,12 @@ def _demix(X, W):
     return np.einsum("tfm,fmk->tfk", X.astype(np.complex128), np.conj(W.astype(np.complex128)))
 
 
+@pytest.mark.needs('W_c128_{model}_{n_iter}')
 @pytest.mark.parametrize("model", ["laplace", "gauss"])
 @pytest.mark.parametrize("n_iter", [0, 1, 2, 5, 20])
 @pytest.mark.parametrize("dt", ["c64", "c128"])
 def test_overiva_matches_reference(oa, golden, model, n_iter, dt):
     """default arithmetic against the real reference's stored results"""
-    need(golden, f"W_c128_{model}_{n_iter}")
     if chaotic(golden, model, n_iter):
         pytest.skip("reference is ill-conditioned here (see conftest.chaotic)")
     X, K = golden["X"], int(golden["K"])
@@ -240,11 +239,11 @@ def test_overiva_matches_reference(oa, golden, model, n_iter, dt):
         assert e64 < max(TOL, 1.5 * floor)      # as close to the reference's complex64 run as its own noise allows
 
 
+@pytest.mark.needs('W_c128_{model}_{n_iter}', 'W_c64_{model}_{n_iter}')
 @pytest.mark.parametrize("model", ["laplace", "gauss"])
 @pytest.mark.parametrize("n_iter", [1, 5, 20])
 def test_fast_mode_accuracy(oa, golden, fast_mode, model, n_iter):
     """the float32 mode: 1e-5 where the reference is well conditioned, a documented envelope elsewhere"""
-    need(golden, f"W_c128_{model}_{n_iter}", f"W_c64_{model}_{n_iter}")
     if chaotic(golden, model, n_iter):
         pytest.skip("reference is ill-conditioned here (see conftest.chaotic)")
     X, K = golden["X"], int(golden["K"])
@@ -259,9 +258,9 @@ def test_fast_mode_accuracy(oa, golden, fast_mode, model, n_iter):
     assert e128 < max(TOL, FAST_FLOORS * floor)
 
 
+@pytest.mark.needs('Ypb_c128_{model}_12')
 @pytest.mark.parametrize("model", ["laplace", "gauss"])
 def test_proj_back_and_callback(oa, golden, model):
-    need(golden, f"Ypb_c128_{model}_12")
     if chaotic(golden, model, 12):
         pytest.skip("reference is ill-conditioned here (see conftest.chaotic)")
     X, K = golden["X"], int(golden["K"])
@@ -280,9 +279,9 @@ def test_proj_back_and_callback(oa, golden, model):
         assert orc.rel_err(got[1], golden["cb10_c128_laplace"]) < bound
 
 
+@pytest.mark.needs('Ypb_frame0_c128_laplace_12')
 def test_frame0_of_large_fixtures(oa, golden):
     """the F >= 64 fixtures keep frame 0 of the projected-back outputs (pins z of every bin and source)"""
-    need(golden, "Ypb_frame0_c128_laplace_12")
     X, K = golden["X"].astype(np.complex128), int(golden["K"])
     Y = oa.overiva(X, n_src=K, n_iter=12, proj_back=True, model="laplace")
     e = orc.rel_err(Y[0], golden["Ypb_frame0_c128_laplace_12"])
@@ -294,8 +293,8 @@ def test_frame0_of_large_fixtures(oa, golden):
     assert e < _bound128(golden, "laplace", 20) and ep < 2 * _bound128(golden, "laplace", 20)
 
 
+@pytest.mark.needs('W0')
 def test_warm_start_default_nsrc_eig(oa, golden):
-    need(golden, "W0")
     X, K = golden["X"], int(golden["K"])
     X128 = X.astype(np.complex128)
     _, W = oa.overiva(X128, n_src=K, n_iter=3, proj_back=False, W0=golden["W0"], return_filters=True)
@@ -313,8 +312,8 @@ def test_warm_start_default_nsrc_eig(oa, golden):
     assert e0 < b and e1 < b and e2 < b
 
 
+@pytest.mark.needs('Ypca_c128_laplace_5')
 def test_auxiva_pca(oa, golden):
-    need(golden, "Ypca_c128_laplace_5")
     X, K = golden["X"], int(golden["K"])
     Y = oa.auxiva_pca(X.astype(np.complex128), n_src=K, n_iter=5, proj_back=True, model="laplace")
     assert Y.shape == golden["Ypca_c128_laplace_5"].shape and Y.dtype == np.complex128

@@ -21,11 +21,11 @@ def _case(g):
     return g["X"], int(g["K"])
 
 
+@pytest.mark.needs('W_c128_{model}_{n_iter}')
 @pytest.mark.parametrize("model", MODELS)
 @pytest.mark.parametrize("n_iter", (0, 1, 2, 5, 20))
 def test_faithful_c128_W(golden, model, n_iter):
     X, K = _case(golden)
-    need(golden, f"W_c128_{model}_{n_iter}")
     if chaotic(golden, model, n_iter):
         pytest.skip("reference is ill-conditioned here (see conftest.chaotic)")
     Y, W = orc.overiva_faithful(X.astype(np.complex128), n_src=K, n_iter=n_iter, proj_back=False,
@@ -37,13 +37,12 @@ def test_faithful_c128_W(golden, model, n_iter):
         assert orc.rel_err(Y, golden[f"Y_c128_{model}_20"]) < TOL128
 
 
+@pytest.mark.needs('W_c128_{model}_{n_iter}')
 @pytest.mark.parametrize("model", MODELS)
 @pytest.mark.parametrize("n_iter", (0, 1, 5, 20))
 def test_faithful_c64_W(golden, model, n_iter):
     X, K = _case(golden)
     key = f"c64_{model}_{n_iter}"
-    if key not in set(golden["nonfinite"].tolist()):
-        need(golden, f"W_{key}")
     if key in set(golden["nonfinite"].tolist()):
         pytest.skip("the reference itself diverged to NaN on this input in complex64")
     if chaotic(golden, model, n_iter):
@@ -73,10 +72,10 @@ def test_staged_matches_reference(golden, model):
             assert orc.rel_err(Y, golden[f"Y_c128_{model}_20"]) < 1e-8
 
 
+@pytest.mark.needs('Ypb_c128_{model}_12')
 @pytest.mark.parametrize("model", MODELS)
 def test_proj_back_and_callback(golden, model):
     X, K = _case(golden)
-    need(golden, f"Ypb_c128_{model}_12")
     if chaotic(golden, model, 12):
         pytest.skip("reference is ill-conditioned here (see conftest.chaotic)")
     got = []
@@ -91,9 +90,9 @@ def test_proj_back_and_callback(golden, model):
     assert orc.rel_err(Y2, golden[f"Ypb_c128_{model}_12"]) < 1e-8
 
 
+@pytest.mark.needs('W0')
 def test_warm_start_default_nsrc_and_eig(golden):
     X, K = _case(golden)
-    need(golden, "W0")
     X = X.astype(np.complex128)
     _, W = orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=False, W0=golden["W0"], return_filters=True)
     assert orc.rel_err(W, golden["W_w0_c128_laplace_3"]) < TOL128
@@ -119,12 +118,11 @@ def test_auxiva_pca(golden):
         orc.auxiva_pca_faithful(X.astype(np.complex128), n_src=K, n_iter=1)
 
 
+@pytest.mark.needs("im_{model}_e0_s0_V")
 @pytest.mark.parametrize("model", MODELS)
 def test_stage_oracles_against_traced_intermediates(golden, model):
     """weighted_cov_all / finalize_activation / ip_update_bin vs V, r_inv, W_hat captured inside the
     reference at overiva.py:181 for every (epoch, source)."""
-    if f"im_{model}_e0_s0_V" not in golden:
-        pytest.skip("no traced intermediates in this fixture")
     X, K = _case(golden)
     X = X.astype(np.complex128)
     T, F, M = X.shape
