@@ -448,18 +448,33 @@ hipError_t launch_bg_one(hipStream_t s, const UpdateArgs& a) {
     return hipGetLastError();
 }
 
-template <int MP>
-hipError_t launch_sq(hipStream_t s, const UpdateArgs& a) {
+// channel count MT (MP / 2 < MT <= MP) as a compile-time constant, and with it the source counts the reference's own
+// sweeps use (overiva_sim_config.json: 2..8 microphones, 1..4 targets, determined AuxIVA): 1, 2, 3, 4, MT
+template <int MP, int MT>
+hipError_t launch_sq_m(hipStream_t s, const UpdateArgs& a) {
     // 1 or 2 sources with background channels: the structured chain (the J initialisation of the prologue keeps
     // the generic kernel)
-    if (!a.init_only && a.K < a.M && MP >= 4) {
-        if (a.K == 2) return a.M == MP ? launch_bg_one<MP, MP, 2>(s, a) : launch_bg_one<MP, 0, 2>(s, a);
-        if (a.K == 1) return a.M == MP ? launch_bg_one<MP, MP, 1>(s, a) : launch_bg_one<MP, 0, 1>(s, a);
+    if constexpr (MP >= 4) {
+        if (!a.init_only && a.K < MT) {
+            if (a.K == 2) return launch_bg_one<MP, MT, 2>(s, a);
+            if (a.K == 1) return launch_bg_one<MP, MT, 1>(s, a);
+        }
     }
-    if (a.M == MP) {
-        if (a.K == 2 && MP >= 2) return launch_sq_one<MP, MP, 2>(s, a);
-        if (a.K == MP) return launch_sq_one<MP, MP, MP>(s, a);
-        if (a.K == 1) return launch_sq_one<MP, MP, 1>(s, a);
+    if (a.K == MT) return launch_sq_one<MP, MT, MT>(s, a);
+    if constexpr (MT > 1) if (a.K == 1) return launch_sq_one<MP, MT, 1>(s, a);
+    if constexpr (MT > 2) if (a.K == 2) return launch_sq_one<MP, MT, 2>(s, a);
+    if constexpr (MT > 3) if (a.K == 3) return launch_sq_one<MP, MT, 3>(s, a);
+    if constexpr (MT > 4) if (a.K == 4) return launch_sq_one<MP, MT, 4>(s, a);
+    return launch_sq_one<MP, MT, 0>(s, a);
+}
+
+template <int MP>
+hipError_t launch_sq(hipStream_t s, const UpdateArgs& a) {
+    if (a.M == MP) return launch_sq_m<MP, MP>(s, a);
+    if constexpr (MP >= 4) if (a.M == MP - 1) return launch_sq_m<MP, MP - 1>(s, a);
+    if constexpr (MP >= 8) {
+        if (a.M == MP - 2) return launch_sq_m<MP, MP - 2>(s, a);
+        if (a.M == MP - 3) return launch_sq_m<MP, MP - 3>(s, a);
     }
     return launch_sq_one<MP, 0, 0>(s, a);
 }
