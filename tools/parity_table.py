@@ -15,9 +15,9 @@ print("# Achieved parity errors (MI355X, round 3)\n")
 print("Source: `tests/test_gpu_parity.py` run with `OIVA_PARITY_LOG` on the GPU box; distances are relative Frobenius")
 print("norms.  `floor` = distance between the REAL reference's complex64 and complex128 results on the fixture")
 print("(stored by `tests/golden/make_golden.py`); `amp` = the reference's own amplification of a 1e-12 input")
-print("perturbation.  Default arithmetic (`auto`): complex64 input runs `mixed` up to 8 channels (float32 products and lane")
-print("chains, float64 sums and per-bin algebra; the X-resident kernel where the shape qualifies) and `precise` for 9-16")
-print("channels; complex128 input runs `precise`.  `fast` = float32 per-bin algebra too.\n")
+print("perturbation.  Default arithmetic (`auto`): complex64 input runs `mixed` at every channel count (float32 products and lane")
+print("chains, float64 sums and per-bin algebra; the X-resident kernel where the shape qualifies); complex128 input runs")
+print("`precise`.  `fast` = float32 per-bin algebra too.\n")
 print("## overiva(), complex64 input (the default mode of that input), final W after n_iter iterations\n")
 print("| fixture | model | n_iter | amp | mode | reference c64 floor | W vs reference-c64 | in floors | W vs c128 | in floors | Y vs c128 | fast: W vs c128 | in floors |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
