@@ -262,11 +262,12 @@ hipError_t pow_blocks_per_cu(int M, int kp, int tcp, int* n) {
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_power(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K,
-                        const PowGeom& g) {
+hipError_t launch_power(hipStream_t s, const float2* X, const float2* Xpad, const float2* What, float* Ppart, int T, int F, int M,
+                        int K, const PowGeom& g) {
     // more than 4 sources would take several VALU passes over X (register budget): one MFMA pass instead
-    // (measured at 16 channels: 16 sources 770 -> 325 us; 2 sources 191 us VALU vs 332 us MFMA)
-    if (M > 8 && K > 4) return launch_power_mfma(s, X, What, Ppart, T, F, M, K);
+    // (measured at 16 channels: 16 sources 770 -> 325 us; 2 sources 191 us VALU vs 332 us MFMA); an odd channel count
+    // reads the copy of X padded by one zero channel (16-byte loads instead of 8-byte ones)
+    if (M > 8 && K > 4) return Xpad ? launch_power_mfma(s, Xpad, What, Ppart, T, F, M, M + 1, K) : launch_power_mfma(s, X, What, Ppart, T, F, M, M, K);
 #define CALL(MM)                                                                                        \
     if (g.kp == 1) return launch_power_one<MM, 1>(s, X, What, Ppart, T, F, K, g);                       \
     if (g.kp == 2) return launch_power_one<MM, 2>(s, X, What, Ppart, T, F, K, g);                       \

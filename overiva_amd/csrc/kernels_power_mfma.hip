@@ -18,9 +18,10 @@ constexpr int kBinsPerBatch = kBinsPerWave * kWaves;   // 64: same batches (and 
 // while the MFMAs of this one run.  The contraction order is free, so lane (j, q) takes the four CONSECUTIVE channels
 // m = 4q + c, c = 0..3, as its share of the four chunks: its 32 bytes of a frame are two 16-byte loads (a chunk of every
 // fourth channel would be four 8-byte loads 32 bytes apart).
-template <bool VEC, int TILES, int GROUP>   // VEC: channels a multiple of 4, rows start and end on 16-byte boundaries
+// Mp: channel pitch of X (>= M; an odd channel count reads the plan's copy of X padded by one zero channel, Mp = M + 1)
+template <bool VEC, int TILES, int GROUP>   // VEC: even pitch -- a lane's channel quarter starts on a 16-byte boundary
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void power_mfma_kernel(
-    const float2* __restrict__ X, const float2* __restrict__ What, float* __restrict__ Ppart, int T, int F, int M, int K) {
+    const float2* __restrict__ X, const float2* __restrict__ What, float* __restrict__ Ppart, int T, int F, int M, int Mp, int K) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int j = lane & 15;             // A: source (row) | B: frame (column)
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int tl = 0; tl < TILES; ++tl) {
         const int t = t0 + 16 * tl;
-        px[tl] = X + ((size_t)(t < T ? t : T - 1) * F + f0) * M + (4 * q < M ? 4 * q : 0);   // + b*M (+ c)
+        px[tl] = X + ((size_t)(t < T ? t : T - 1) * F + f0) * Mp + (4 * q < Mp ? 4 * q : 0);   // + b*Mp (+ c)
     }
     const float2* pw = What + (size_t)f0 * M * M;                                            // + (b*M + m)*M + k
     float P[TILES][4];                   // sources 4q..4q+3 at frame t0 + 16 tl
@@ -54,15 +55,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int g = 0; g < GROUP; ++g) {
                 const int b = b0 + g < nbins ? b0 + g : nbins - 1;
                 if constexpr (VEC) {
-                    const float4* p = reinterpret_cast<const float4*>(px[tl] + (size_t)b * M);
-                    const float4 lo = p[0], hi = p[1];
+                    // (a pitch that is no multiple of 4: the last quarter holds two channels, its second load repeats the
+                    //  first instead of running past the bin -- those channels meet a zero in W)
+                    const float4* p = reinterpret_cast<const float4*>(px[tl] + (size_t)b * Mp);
+                    const float4 lo = p[0], hi = p[4 * q + 2 < Mp ? 1 : 0];
                     o.x[tl][g][0] = make_float2(lo.x, lo.y);
                     o.x[tl][g][1] = make_float2(lo.z, lo.w);
                     o.x[tl][g][2] = make_float2(hi.x, hi.y);
                     o.x[tl][g][3] = make_float2(hi.z, hi.w);
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o.x[tl][g][c] = px[tl][(size_t)b * M + (4 * q + c < M ? c : 0)];
+                    for (int c = 0; c < 4; ++c) o.x[tl][g][c] = px[tl][(size_t)b * Mp + (4 * q + c < Mp ? c : 0)];
                 }
             }
 #pragma unroll
@@ -147,20 +150,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 }  // namespace
 
 template <int TILES, int GROUP>
-static hipError_t launch_shape(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K) {
+static hipError_t launch_shape(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int Mp, int K) {
     dim3 grid((F + kBinsPerBatch - 1) / kBinsPerBatch, (T + 16 * kWaves * TILES - 1) / (16 * kWaves * TILES));
-    if ((M & 3) == 0)
-        power_mfma_kernel<true, TILES, GROUP><<<grid, dim3(kBlock), 0, s>>>(X, What, Ppart, T, F, M, K);
+    if ((Mp & 1) == 0)
+        power_mfma_kernel<true, TILES, GROUP><<<grid, dim3(kBlock), 0, s>>>(X, What, Ppart, T, F, M, Mp, K);
     else
-        power_mfma_kernel<false, TILES, GROUP><<<grid, dim3(kBlock), 0, s>>>(X, What, Ppart, T, F, M, K);
+        power_mfma_kernel<false, TILES, GROUP><<<grid, dim3(kBlock), 0, s>>>(X, What, Ppart, T, F, M, Mp, K);
     return hipGetLastError();
 }
 
-hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K) {
+hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int Mp, int K) {
     // measured at 2048 x 4000 x 16 / 16 (tiles x bins per group): 4x1 252 us, 2x1 252, 2x2 267, 1x2 279, 1x4 306 -- the
     // W operands come from L2 once per wave and bin, so more frames per wave is less W traffic (W-only 81 us at 1x4);
     // X alone streams in 199 us, the MFMAs alone take 134 us
-    return launch_shape<4, 1>(s, X, What, Ppart, T, F, M, K);
+    return launch_shape<4, 1>(s, X, What, Ppart, T, F, M, Mp, K);
 }
 
 }  // namespace oiva

@@ -139,10 +139,11 @@ bool cov_supported(int M);
 
 // Demix + source power, overiva.py:140 + the norms at :153/:155.
 //   What (F,M,M) c64 row-major;  Ppart [nb][T][K]
-hipError_t launch_power(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M,
+//   Xpad: (T, F, M + 1) zero-padded copy of X (odd 9..15 channels, many sources) or nullptr
+hipError_t launch_power(hipStream_t s, const float2* X, const float2* Xpad, const float2* What, float* Ppart, int T, int F, int M,
                         int K, const PowGeom& g);
 // matrix-core variant for 9..16 channels (same Ppart layout, one pass over X for all sources)
-hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int K);
+hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int Mp, int K);
 int pow_sources_per_pass(int M, int K);
 hipError_t pow_blocks_per_cu(int M, int kp, int tcp, int* n);
 

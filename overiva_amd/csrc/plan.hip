@@ -318,7 +318,7 @@ int ensure_vpart(oiva_plan* p) {
 
 // ---- the five stages of one iteration -----------------------------------------------------------
 int stage_power(oiva_plan* p) {
-    HIP_TRY(launch_power(p->stream, p->X, p->What, p->Ppart, p->T, p->F, p->M, p->K, p->pw));
+    HIP_TRY(launch_power(p->stream, p->X, p->X_pad && p->pad_valid ? p->X_pad : nullptr, p->What, p->Ppart, p->T, p->F, p->M, p->K, p->pw));
     return OIVA_OK;
 }
 int stage_activation(oiva_plan* p, const float* parts, int nparts) {

@@ -138,6 +138,26 @@ def test_demix_power(oa, golden):
     assert orc.rel_err(pw, ref) < TOL_KERNEL
 
 
+@pytest.mark.parametrize("before_covariance", [False, True], ids=["padded-copy", "caller-X"])
+@pytest.mark.parametrize("shape", [(70, 5, 10, 10), (33, 3, 14, 9), (50, 70, 9, 9), (64, 65, 13, 6), (40, 2, 15, 15), (40, 7, 11, 11),
+                                   (100, 9, 12, 5), (17, 1, 16, 16), (65, 64, 10, 5)], ids=lambda s: "x".join(str(v) for v in s))
+def test_power_pass_of_many_sources_at_every_channel_count(oa, shape, before_covariance):
+    """the matrix-core power pass (9..16 channels, more than 4 sources; overiva.py:140 + :153): 16-byte loads at every even
+    channel pitch (10 and 14 channels: the last channel quarter holds two), odd channel counts on the plan's zero-padded copy
+    of X once oiva_plan_covariance has filled it and on the caller's X before; ragged bins, frames and sources"""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F, M, seed=3)
+    rng = np.random.default_rng(6)
+    What = (rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M))).astype(np.complex64)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_x(X)
+        if not before_covariance:
+            p.covariance()
+        p.t_set_what(What)
+        pw = p.t_run_power()
+    assert orc.rel_err(pw, orc.demix_power(X, What[:, :, :K])) < TOL_KERNEL
+
+
 @pytest.mark.needs("im_{model}_e0_s0_V")
 @pytest.mark.parametrize("rows", [False, True], ids=["lane-per-element", "lane-per-row"])
 @pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
