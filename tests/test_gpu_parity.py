@@ -733,11 +733,24 @@ def test_cfg5_full_size_properties(oa, mode):
 @pytest.fixture(scope="module")
 def headline_mixture():
     """2048 x 4000 x 8 / 2 mixture-like input and the oracle's results after 20 iterations: the reference's own arithmetic
-    for complex64 input (reference-faithful form) and its complex128 result (about a minute of CPU work, shared)"""
-    T, F, M, K = 4000, 2048, 8, 2
-    X = orc.synth_mixture(T, F, M, K, seed=21)
-    _, W64 = orc.overiva_faithful(X, n_src=K, n_iter=20, proj_back=False, return_filters=True)
-    _, W128 = orc.overiva_staged(X.astype(np.complex128), n_src=K, n_iter=20, proj_back=False, return_filters=True)
+    for complex64 input (reference-faithful form) and its complex128 result.  Two minutes of CPU work on the GPU box: taken
+    from tests/golden/headline_mixture20.npz (written by make_headline_mixture.py from the same oracle calls) when the
+    regenerated input has the digest stored there, computed here otherwise"""
+    import importlib.util
+    import os
+
+    from conftest import GOLDEN_DIR
+
+    spec = importlib.util.spec_from_file_location("make_headline_mixture", os.path.join(GOLDEN_DIR, "make_headline_mixture.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    (T, F, M, K), seed = mk.SHAPE, mk.SEED
+    X = orc.synth_mixture(T, F, M, K, seed=seed)
+    if os.path.exists(mk.OUT):
+        with np.load(mk.OUT) as d:
+            if str(d["x_digest"]) == mk.x_digest(X) and int(d["n_iter"]) == 20:
+                return X, d["W64"], d["W128"]
+    W64, W128 = mk.compute(X, K)
     return X, W64, W128
 
 

@@ -170,3 +170,19 @@ def test_invariants(golden):
     if K < M:   # W^H Cx [J; -I] = 0
         B = W_hat[:, :, K:]
         assert np.allclose(np.conj(np.swapaxes(W_hat[:, :, :K], 1, 2)) @ Cx @ B, 0.0, atol=1e-9)
+
+
+def test_headline_mixture_expectations_file():
+    """tests/golden/headline_mixture20.npz (make_headline_mixture.py): the oracle's own results for the full-size mixture test
+    of the GPU suite, stored so that the GPU run does not spend two minutes of CPU time on them; the GPU test regenerates
+    the input and recomputes when its digest differs"""
+    import os
+
+    from conftest import GOLDEN_DIR
+
+    with np.load(os.path.join(GOLDEN_DIR, "headline_mixture20.npz")) as d:
+        W64, W128 = d["W64"], d["W128"]
+        assert tuple(d["shape"]) == (4000, 2048, 8, 2) and int(d["n_iter"]) == 20 and len(str(d["x_digest"])) == 64
+    assert W64.shape == W128.shape == (2048, 8, 2) and W64.dtype == np.complex64 and W128.dtype == np.complex128
+    assert np.all(np.isfinite(W64)) and np.all(np.isfinite(W128))
+    assert 1e-6 < orc.rel_err(W64, W128) < 1e-3          # the reference's complex64 floor on this input (2.9e-5)
