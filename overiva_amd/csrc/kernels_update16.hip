@@ -226,7 +226,9 @@ __global__ __launch_bounds__(64) void update_wave16_kernel(UpdateArgs a) {
     // values 4l .. 4l + 3 of each block (16-byte loads when M is even), the splits are added in order in float64, the
     // sum goes to LDS and every lane gathers its four entries.  The loads of source s + 1 are in flight while source s
     // is solved.
-    constexpr int kAhead = 8;                                 // splits held in registers across a solve
+    // splits held in registers across a solve.  (float64 partials + float64 algebra + background rows: 8 of them made 255
+    // registers and ONE wave per SIMD -- two rounds of bins at 2048 bins; with 4 the kernel fits two waves per SIMD)
+    constexpr int kAhead = (OVER && sizeof(VT) == 8 && sizeof(R) == 8) ? 4 : 8;
     const VT* vbase = static_cast<const VT*>(a.Vpart);
     const size_t vstride = (size_t)a.F * K * NA;
     const int nahead = a.nsplit < kAhead ? a.nsplit : kAhead;
