@@ -31,12 +31,22 @@ __device__ __forceinline__ float fast_rcp(float x) {
     const float r = __builtin_amdgcn_rcpf(x);
     return fmaf(r, fmaf(-x, r, 1.f), r);
 }
-__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+// double: the hardware seed (v_rcp_f64 / v_rsq_f64, > 26 bits) and two Newton steps -- the last bits of a double (the
+// IEEE division costs about thirty dependent instructions, 1 / sqrt about sixty, on the critical path of every step)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
 __device__ __forceinline__ float fast_rsqrt(float x) {
     const float r = __builtin_amdgcn_rsqf(x);
     return fmaf(0.5f * r, fmaf(-x * r, r, 1.f), r);
 }
-__device__ __forceinline__ double fast_rsqrt(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+    return fma(0.5 * r, fma(-x * r, r, 1.0), r);
+}
 
 template <typename R>
 __device__ __forceinline__ Cx<R> cinv(Cx<R> a) {
