@@ -254,10 +254,10 @@ __global__ __launch_bounds__(kBlock, 2) void cov_half16_kernel(const float2* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// float64 form (the `precise` arithmetic, OIVA_PREC_COV_F64) of the same decomposition for more than 4 sources: float64 sums of
-// exact float64 products, EIGHT sources per pass (80 float64 accumulators per lane).  The fp64 matrix-core kernel it
-// replaces there (kernels_cov_mfma.hip) spends 768 multiply-adds per frame and source on a pipe that sustains 44 TFLOP/s;
-// this one 14 conversions + 20 + 10 K float64 vector instructions per lane and frame at 60 TFLOP/s peak.
+// float64 form (the `precise` arithmetic, OIVA_PREC_COV_F64) of the same decomposition for 3..16 sources: float64 sums of
+// exact float64 products, FOUR or EIGHT sources per pass (40 / 80 float64 accumulators per lane).  The fp64 matrix-core
+// kernel it replaces there (kernels_cov_mfma.hip) spends 768 multiply-adds per frame and source on a pipe that sustains
+// 44 TFLOP/s; this one 14 conversions + 20 + 10 NS float64 vector instructions per lane, frame and pass at 60 TFLOP/s peak.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kH64WeightStride = 16;                    // doubles per row of the float64 weight table
 constexpr int kH64Chunk = kH16Chunk / 2;                // doubles per LDS round of the epilogue (same scratch bytes)
