@@ -42,6 +42,7 @@ sys.path.insert(0, REPO)
 MODEL = "laplace"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (= the fp32 vector peak)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # fp64 vector peak of AMD's MI355X data sheet (the guide lists no fp64 figure; measured with tools/pkbench.hip: 60)
 # --config: the headline workload (default; the one BASELINE.json's metric is quoted on) and the other shapes
 CONFIGS = {
     "headline": dict(T=4000, F=2048, M=8, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[2])"),
@@ -238,36 +239,46 @@ def _cov_roofline(shape, mode, cov_ms):
                        "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
                        "note": "co-limited by the vector ALU: 512 real FMAs per (bin, frame, source pair) at 16 channels against 128 at 8"}
     if mode != "precise" and k > 4:
-        # the Hermitian half on the vector ALU, 32 lanes per (bin, frame), every source in one pass: bound by the packed-fp32
-        # issue rate (2 + k instructions per complex entry slot, 160 slots per (bin, frame)), not by memory
+        # the Hermitian half on the vector ALU, 32 lanes per (bin, frame), every source in one pass: bound by fp32 arithmetic
+        # (cfg5's roofline is the 157.3 TFLOP/s fp32 peak, which the packed vector ALU shares with the matrix cores)
         bytes_cov = cov_algorithmic_bytes(t, f, m, k)
-        np_ = 4 if k <= 8 else (6 if k <= 12 else 8)
-        instr = 32.0 * (10 + 10 * np_) * t * f / 64            # packed wave-instructions per launch
-        floor_ms = instr / 1024 * 2.0e-6                       # 1024 SIMDs, 2.0 ns per packed instruction and SIMD (tools/pkbench.hip)
+        np_ = 4 if k <= 8 else (6 if k <= 12 else 8)            # source PAIRS per lane of the instantiation
+        slots = 160.0                                           # complex entry slots per (bin, frame): 32 lanes x 5 (136 entries of the half)
+        issued = slots * (2 + 2 * np_) * 4.0 * t * f            # packed instructions x 4 flop slots each (v_pk_mul_f32 uses 2 of its 4)
+        useful = ((m * (m - 1) // 2) * (6.0 + 4.0 * k) + m * (3.0 + 2.0 * k)) * t * f     # Hermitian half, products formed once
+        naive = 8.0 * k * m * m * t * f                         # naive complex count (268.4 GF at 16 x 16)
+        sec = cov_ms * 1e-3
+        instr = 32.0 * (10 + 10 * np_) * t * f / 64             # packed wave-instructions per launch
+        floor_ms = instr / 1024 * 2.0e-6                        # 1024 SIMDs, 2.0 ns per packed instruction and SIMD (tools/pkbench.hip)
         kname = f"cov_half16_kernel<{np_}, false>"
-        return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, overiva.py:179)",
-                       "achieved": bytes_cov / (cov_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": bytes_cov / (cov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_cov,
-                       "avg_launch_ms": cov_ms,
-                       "vector_alu": {"packed_wave_instructions_per_launch": instr, "issue_floor_ms": floor_ms, "frac_of_issue_floor": floor_ms / cov_ms},
-                       "note": "NOT memory-bound: the vector ALU's packed-fp32 issue rate bounds it (vector_alu); the fp32 matrix cores "
-                               "have the same peak and the planar form needs 2.8x the multiply-adds (it measured 1.69 ms at 16 x 16)"}
+        return kname, {"bound": "fp32", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass on the packed-fp32 vector ALU, overiva.py:179)",
+                       "achieved": issued / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                       "issued_flops_per_launch": issued, "useful_flops_per_launch": useful, "naive_complex_flops_per_launch": naive,
+                       "useful_tflops": useful / sec / 1e12, "frac_useful": useful / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                       "naive_complex_tflops": naive / sec / 1e12, "frac_naive": naive / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                       "algorithmic_bytes_per_launch": bytes_cov, "hbm_gbs": bytes_cov / sec / 1e9, "avg_launch_ms": cov_ms, "traffic": None,
+                       "note": "achieved / frac count ISSUED flop slots of the packed vector ALU against the 157.3 TFLOP/s spec peak (vector = matrix "
+                               "peak on CDNA4; the planar matrix-core form needs 2.8x the multiply-adds and measured 1.69 ms at 16 x 16); useful = "
+                               "Hermitian half with each product formed once; naive = SURVEY 8d's 8 K M^2 T F.  Self-measured issue ceiling, for "
+                               f"orientation only: 2.0 ns per packed instruction and SIMD (tools/pkbench.hip) = {floor_ms:.3f} ms for this launch"}
     if mode == "precise" and k >= 3:
-        # the same lanes with float64 sums of exact products, four or eight sources per pass: bound by the float64 issue rate of
-        # the vector ALU (14 conversions + 20 + 10 * sources float64 instructions per lane and frame)
+        # the same lanes with float64 sums of exact products, four or eight sources per pass: bound by the float64 rate of the
+        # vector ALU (14 conversions + 20 + 10 * sources float64 instructions per lane and frame); peak: 78.6 TFLOP/s fp64 vector
         ns = 4 if k <= 4 else 8
         passes = -(-k // ns)
         bytes_cov = cov_algorithmic_bytes(t, f, m, k) + (passes - 1) * 8 * t * f * m
         instr = 32.0 * (14 + 20 + 10 * ns) * passes * t * f / 64
         floor_ms = instr / 1024 * 2.2e-6                       # 2.2 ns per float64 instruction and SIMD (tools/pkbench.hip)
+        issued = 32.0 * (20 + 10 * ns) * 2.0 * passes * t * f  # float64 FMA slots x 2 flops (conversions not counted)
+        naive = 8.0 * k * m * m * t * f
+        sec = cov_ms * 1e-3
         kname = f"cov_half16f64_kernel<{ns}>"
-        return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance, {ns} sources per pass over X, overiva.py:179)",
-                       "achieved": bytes_cov / (cov_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": bytes_cov / (cov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_cov,
-                       "avg_launch_ms": cov_ms,
-                       "vector_alu": {"f64_wave_instructions_per_launch": instr, "issue_floor_ms": floor_ms, "frac_of_issue_floor": floor_ms / cov_ms},
-                       "note": "NOT memory-bound: the vector ALU's float64 issue rate bounds it (vector_alu); the fp64 matrix-core form "
-                               "it replaces measured 3.1 ms at 16 x 16"}
+        return kname, {"bound": "fp64", "kernel": f"{kname} (weighted spatial covariance, {ns} sources per pass over X, float64 on the vector ALU, overiva.py:179)",
+                       "achieved": issued / sec / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                       "issued_flops_per_launch": issued, "naive_complex_flops_per_launch": naive, "naive_complex_tflops": naive / sec / 1e12,
+                       "algorithmic_bytes_per_launch": bytes_cov, "hbm_gbs": bytes_cov / sec / 1e9, "avg_launch_ms": cov_ms, "traffic": None,
+                       "note": "float64 FMA slots of the vector ALU against its 78.6 TFLOP/s spec peak; the fp64 matrix-core form it replaces measured "
+                               f"3.1 ms at 16 x 16.  Self-measured issue ceiling, for orientation only: 2.2 ns per float64 instruction and SIMD = {floor_ms:.3f} ms"}
     naive = 8.0 * k * m * m * t * f            # complex MACs counted as 8 real flops
     issued = 6.0 * k * m * m * t * f           # what the planar form issues: 3 MFMAs of 16x16x4 per 4 frames and source
     kname = "cov_mfma16_kernel<double, 16>" if mode == "precise" else "cov_mfma16_kernel<float, 16>"
@@ -280,9 +291,28 @@ def _cov_roofline(shape, mode, cov_ms):
                            "avg_launch_ms is the event-bracketed stage (weights pre-pass of ~6 us + the matrix-core kernel)"}
 
 
+def _rates(steps, dts):
+    r = [steps / d for d in dts]
+    return {"value_median": _median(r), "value_min": min(r), "value_max": max(r), "repeats": len(r)}
+
+
+def _time_resident(plan, args, repeats):
+    """the X-resident kernel: W warm-up iterations, then K timed ones = ONE persistent launch, `repeats` more of the same"""
+    plan.iterate(args.warmup)
+    plan.sync()
+    dts = []
+    for _ in range(1 + repeats):
+        t0 = time.perf_counter()
+        plan.iterate(args.steps)
+        plan.sync()
+        dts.append(time.perf_counter() - t0)
+    return dts
+
+
 def _secondary_config(torch, oa, dev, name, args):
-    """one of the other BASELINE configs, same protocol as the headline: the four-launch path (graph replay) and, where the
-    shape qualifies, the X-resident kernel; the faster one is `value`"""
+    """one of the other BASELINE configs, same protocol as the headline (and `--repeats` more measurements of the same K steps
+    for a median): the four-launch path (graph replay) and, where the shape qualifies, the X-resident kernel; the faster one
+    is `value`.  shard8 also runs the kernel's multi-GPU exchange in loop-back (this GPU plays all 8 ranks)."""
     c = CONFIGS[name]
     shape = (c["T"], c["F"], c["M"], c["K"])
     mode = "precise" if name == "cfg0" else ("mixed" if c["M"] <= 8 or name == "m16k2" else args.cfg5_precision)
@@ -290,37 +320,51 @@ def _secondary_config(torch, oa, dev, name, args):
     torch.cuda.synchronize()
     out = {"workload": c["name"].format(**c), "precision": mode, "steps": args.steps, "warmup": args.warmup}
     plan = _make_plan(oa, X, shape, mode, True)
-    dt, total_ms, stages, _ = _time_plan(plan, args)
+    dt, total_ms, stages, more = _time_plan(plan, args, repeats=args.repeats)
     info = plan.resident_info()
     plan.close()
     cov_ms = stages["weighted_cov"] / args.steps
     _, roof = _cov_roofline(shape, mode, cov_ms)
     if name in ("cfg2", "cfg0"):
         roof["note"] = "16 MB of X: resident in L2 / Infinity Cache, the pass is launch- and latency-bound, not a roofline claim"
-    out["four_launch"] = {"value": args.steps / dt, "unit": "iterations/s", "ms_per_step": dt / args.steps * 1e3,
+    out["four_launch"] = {"value": args.steps / dt, "unit": "iterations/s", "ms_per_step": dt / args.steps * 1e3, **_rates(args.steps, [dt] + more),
                           "stage_ms_per_step": {k: v / args.steps for k, v in stages.items()}, "roofline": roof}
     out["value"], out["path"] = args.steps / dt, "four launches per iteration (hipGraph replay)"
+    best = out["four_launch"]
     if info["qualifies"]:
-        plan = _make_plan(oa, X, shape, mode, False, resident=True)
-        plan.iterate(args.warmup)
-        plan.sync()
-        t0 = time.perf_counter()
-        plan.iterate(args.steps)          # ONE persistent launch
-        plan.sync()
-        dtr = time.perf_counter() - t0
-        phases, nit = plan.resident_phases()
-        info = plan.resident_info()
-        plan.close()
-        out["resident"] = {"value": args.steps / dtr, "unit": "iterations/s", "ms_per_step": dtr / args.steps * 1e3,
-                           "phase_us_workgroup0": phases, "grid": [info["bin_groups"], info["frame_splits"]],
-                           "frames_per_lane": info["frames_per_lane"], "frames_in_registers": info["frames_in_registers"],
-                           "lds_bytes": info["lds_bytes"], "x_bytes_per_cu": info["x_bytes_per_cu"], "fallbacks": info["fallbacks"],
-                           "roofline": {"bound": "latency", "frac": None,
-                                        "note": "X stays in registers + LDS for the whole launch: per iteration the kernel moves only the "
-                                                "exchange words (parts, partial covariances, demixing vectors) through L2; what bounds it "
-                                                "is the dependency chain power -> r -> V -> W across workgroups (phase_us_workgroup0)"}}
-        if info["fallbacks"] == 0 and dtr < dt:
-            out["value"], out["path"] = args.steps / dtr, "X-resident persistent launch (one launch for all the timed iterations)"
+        note = {"bound": "latency", "frac": None,
+                "note": "X stays in registers + LDS for the whole launch: per iteration the kernel moves only the exchange words (parts, "
+                        "partial covariances, demixing vectors) through L2; what bounds it is the dependency chain power -> r -> V -> W "
+                        "across workgroups (phase_us_workgroup0)"}
+
+        def resident_entry(loopback):
+            plan = _make_plan(oa, X, shape, mode, False)
+            if loopback:
+                plan.resident_loopback(loopback)
+            plan.set_resident(True)
+            dts = _time_resident(plan, args, args.repeats)
+            phases, nit = plan.resident_phases()
+            inf = plan.resident_info()
+            plan.close()
+            return {"value": args.steps / dts[0], "unit": "iterations/s", "ms_per_step": dts[0] / args.steps * 1e3, **_rates(args.steps, dts),
+                    "phase_us_workgroup0": phases, "grid": [inf["bin_groups"], inf["frame_splits"]],
+                    "frames_per_lane": inf["frames_per_lane"], "frames_in_registers": inf["frames_in_registers"],
+                    "lds_bytes": inf["lds_bytes"], "x_bytes_per_cu": inf["x_bytes_per_cu"], "fallbacks": inf["fallbacks"], "roofline": note}
+
+        out["resident"] = resident_entry(0)
+        if out["resident"]["fallbacks"] == 0 and out["resident"]["value"] > out["value"]:
+            out["value"], out["path"] = out["resident"]["value"], "X-resident persistent launch (one launch for all the timed iterations)"
+            best = out["resident"]
+        if name == "shard8":
+            try:
+                out["resident_loopback8"] = resident_entry(8)
+                out["resident_loopback8"]["what"] = ("the kernel's MULTI-GPU exchange on one GPU: per frame split a leader workgroup gathers the "
+                                                     "rank's parts and stores the sums of 8 slots (its own, zeros for the 7 phantom ranks) into a "
+                                                     "fine-grained gather buffer; every workgroup polls its words of all 8 slots and adds them in rank "
+                                                     "order -- what every rank of `bench.py --gpus 8` runs, minus the flight over xGMI")
+            except Exception as e:
+                out["resident_loopback8"] = {"error": f"{type(e).__name__}: {e}"}
+    out.update({k: best[k] for k in ("value_median", "value_min", "value_max", "repeats")})
     out["unit"] = "iterations/s"
     return out
 
@@ -345,11 +389,12 @@ def run_single(args):
             if other == args.precision:
                 continue
             plan = _make_plan(oa, X, shape, other, args.graph)
-            dt2, total2, stages2, _ = _time_plan(plan, args)
+            dt2, total2, stages2, more2 = _time_plan(plan, args, repeats=args.repeats)
             plan.close()
             cov2 = stages2["weighted_cov"] / args.steps
             _, roof2 = _cov_roofline(shape, other, cov2)
             other_modes.append({"precision": other, "value": args.steps / dt2, "unit": "iterations/s", "ms_per_step": dt2 / args.steps * 1e3,
+                                **_rates(args.steps, [dt2] + more2),
                                 "stage_ms_per_step": {k: v / args.steps for k, v in stages2.items()},
                                 "roofline": {k: roof2[k] for k in ("bound", "kernel", "achieved", "unit", "frac")}})
     plan = _make_plan(oa, X, shape, args.precision, args.graph)
@@ -371,10 +416,11 @@ def run_single(args):
     roofline.update({"stage_ms_per_step": per_step, "event_timed_ms_per_step": total_ms / args.steps, "cov_splits": splits})
     out = result_line(args, 1, dt)
     if more:
-        rates = [args.steps / d for d in [dt] + more]
-        out["value_median"], out["repeats"] = _median(rates), len(rates)
-        out["value_min"], out["value_max"] = min(rates), max(rates)
+        out.update(_rates(args.steps, [dt] + more))
     out["roofline"] = roofline
+    # (the driver's record keeps the scalars of `config`: the other arithmetic modes' rates on the same workload go there too)
+    for om in other_modes:
+        out["config"][f"iterations_per_s_{om['precision']}"] = om["value"]
     if other_modes:
         out["other_modes"] = other_modes
     del X
@@ -384,6 +430,10 @@ def run_single(args):
         for name in ("cfg0", "cfg2", "shard8", "cfg5", "m16k2"):
             try:
                 out["configs"][name] = _secondary_config(torch, oa, dev, name, args)
+                out["config"][f"iterations_per_s_{name}"] = out["configs"][name]["value"]
+                lb = out["configs"][name].get("resident_loopback8", {}).get("value")
+                if lb:
+                    out["config"][f"iterations_per_s_{name}_loopback8"] = lb
             except Exception as e:  # a secondary shape must not cost the headline line
                 out["configs"][name] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()

@@ -241,8 +241,16 @@ int oiva_plan_set_precision(oiva_plan *p, int flags);
  *                              [3] weighted covariance: accumulation, [4] its reduction over the frame phases + publication,
  *                              [5] wait for the row's partials, [6] per-bin update chain, [7] wait for the row's
  *                              demixing vectors; *n_iter = iterations covered (0: nothing recorded)
- *   oiva_plan_resident_debug : test hooks -- time-out of a wait in milliseconds (0: default 2000), and the index of a
- *                              workgroup that never publishes (-1: none), which makes the launch give up
+ *   oiva_plan_resident_debug : test hooks -- time-out of a wait in milliseconds (0: default 250, 2000 when sharded over processes), and the index of a
+ *                              workgroup that never publishes (-1: none), which makes the launch give up;
+ *                              _debug_from: the workgroup stops publishing in that iteration of a launch (0-based)
+ *   oiva_plan_resident_loopback: world >= 2: ONE GPU runs the multi-GPU exchange of the kernel against itself -- per
+ *                              frame split a leader workgroup gathers the rank's parts and stores the sums of all
+ *                              `world` slots (its own, exact zeros for the others) into a gather buffer of the same kind
+ *                              of memory the ranks of a sharded run map from each other, every workgroup adds the
+ *                              slots in rank order: the leader hop and the world-slot sum of bench.py --gpus N on one
+ *                              GPU (everything but the flight over xGMI), with the result of world = 1.  0 / 1: off.
+ *                              Call it while resident is off; the plan must own all bins.
  */
 struct oiva_xchg;
 #define OIVA_RESIDENT_INFO 12
@@ -251,6 +259,8 @@ int oiva_plan_set_resident(oiva_plan *p, int enable);
 int oiva_plan_resident_info(oiva_plan *p, int *info /* OIVA_RESIDENT_INFO ints */);
 int oiva_plan_resident_phases(oiva_plan *p, double *phase_us /* OIVA_RESIDENT_PHASES */, int *n_iter);
 int oiva_plan_resident_debug(oiva_plan *p, int timeout_ms, int stall_block);
+int oiva_plan_resident_debug_from(oiva_plan *p, int timeout_ms, int stall_block, int first_stalled_iteration);
+int oiva_plan_resident_loopback(oiva_plan *p, int world);
 /* Diagnostics: with enable != 0 the next resident launches (of at most 64 iterations) record the timestamps of EVERY
  * workgroup; stamps_host (NULL: just switch) receives [n_wg][n_iter][OIVA_RESIDENT_STAMPS] 100 MHz ticks of the last one. */
 #define OIVA_RESIDENT_STAMPS 10

@@ -7,11 +7,6 @@ product path fails with an explicit error.  ``python -m overiva_amd.build`` (or
 import ctypes as C
 import os
 
-# The host driver of this platform supports dmabuf IPC only: without this setting hipIpcGetMemHandle (the push exchange,
-# RCCL, sharing device tensors across processes) fails with "invalid argument".  It must be in the environment before
-# the HIP runtime initialises, i.e. before the first GPU call of the process.
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -82,6 +77,8 @@ SIGNATURES = {
     "oiva_plan_resident_info": [_vp, C.POINTER(_i)],
     "oiva_plan_resident_phases": [_vp, C.POINTER(C.c_double), C.POINTER(_i)],
     "oiva_plan_resident_debug": [_vp, _i, _i],
+    "oiva_plan_resident_debug_from": [_vp, _i, _i, _i],
+    "oiva_plan_resident_loopback": [_vp, _i],
     "oiva_plan_resident_connect": [_vp, _vp],
     "oiva_plan_resident_trace": [_vp, _i, _vp, C.POINTER(_i), C.POINTER(_i)],
     "oiva_plan_set_resident_splits": [_vp, _i],
@@ -135,6 +132,31 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def require_dmabuf_ipc(what):
+    """The host driver of this platform exports device memory through dmabuf only: ``hipIpcGetMemHandle`` (the push
+    exchange and the X-resident kernel's exchange between processes, RCCL, device tensors shared across processes) fails
+    with "invalid argument" unless ``HSA_ENABLE_IPC_MODE_LEGACY=0`` is in the environment BEFORE the process's first GPU
+    call.  Importing the package does not touch the environment; the multi-process exchanges call this when they are asked
+    for: it sets the variable if it is unset (effective only if HIP has not initialised yet -- launchers such as
+    ``bench.py --gpus N`` export it for their ranks) and warns when it holds another value."""
+    import warnings
+
+    cur = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    if cur is None:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        try:
+            import torch
+
+            started = torch.cuda.is_initialized()
+        except Exception:
+            started = False
+        if started:
+            warnings.warn(f"{what}: HSA_ENABLE_IPC_MODE_LEGACY=0 was not in the environment when the GPU runtime started; "
+                          "exporting device memory to other processes may fail (export it before launching)")
+    elif cur != "0":
+        warnings.warn(f"{what}: HSA_ENABLE_IPC_MODE_LEGACY={cur!r}; this platform's driver supports dmabuf IPC (=0) only")
 
 
 def check(rc):

@@ -45,14 +45,31 @@ def _compile(src, extra=()):
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     extra = tuple(extra) + tuple(EXTRA_FLAGS.get(src, ())) + tuple(os.environ.get("OIVA_EXTRA_" + src.split(".")[0].upper(), "").split())
-    if _stale(obj, [path] + HEADERS):
-        cmd = [_hipcc(), *FLAGS, *extra, "-c", path, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *extra, "-c", path, "-o", obj]
+    # the command line is part of what an object depends on: a change of the per-file flags recompiles
+    stamp = os.path.splitext(obj)[0] + ".cmd"
+    same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+    if not same_cmd or _stale(obj, [path] + HEADERS):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        with open(stamp, "w") as f:
+            f.write(" ".join(cmd))
         if "-Rpass-analysis=kernel-resource-usage" in extra:
+            # the resource remarks go next to the object; everything else the compiler said (warnings) is shown as usual
+            remarks, rest, in_remark = [], [], False
+            for line in r.stderr.splitlines(keepends=True):
+                if "remark:" in line and "kernel-resource-usage" in line:
+                    remarks.append(line)
+                else:
+                    rest.append(line)
+            # (clang prints a source excerpt + caret under every remark: drop those lines too)
+            shown = [l for l in rest if l.strip() and not l.lstrip().startswith(("__global__", "^", "|")) and "remarks generated" not in l
+                     and not l.lstrip()[:1].isdigit()]
             with open(os.path.splitext(obj)[0] + ".usage.txt", "w") as f:
-                f.write(r.stderr)
+                f.writelines(remarks)
+            if shown:
+                sys.stderr.writelines(shown)
         elif r.stderr.strip():
             sys.stderr.write(r.stderr)
     return obj

@@ -113,11 +113,15 @@ struct oiva_plan {
     double* res_rsum = nullptr;
     float2* res_wpub = nullptr;
     unsigned* res_flags = nullptr; // ctrl words ([0] give-up code)
+    float2* res_what = nullptr;    // staging copies of the final W_hat of a launch (moved into What / What64 when nobody gave up)
+    double2* res_what64 = nullptr;
     unsigned long long* res_stamps = nullptr;
     size_t res_block_bytes = 0;
     unsigned res_epoch = 0;
     int res_last_code = 0, res_launches = 0, res_fallbacks = 0, res_stamped = 0;
-    int res_timeout_ms = 0, res_stall = -1;
+    int res_timeout_ms = 0, res_stall = -1, res_stall_iter = 0;
+    char* res_loop_buf = nullptr;  // loop-back: this plan plays all res_world ranks on one GPU (oiva_plan_resident_loopback)
+    bool res_loopback = false;
     bool res_trace = false;        // timestamps of every workgroup (oiva_plan_resident_trace)
     unsigned long long* res_trace_buf = nullptr;
     int res_trace_iters = 0;
@@ -383,7 +387,8 @@ int resident_alloc(oiva_plan* p) {
     const size_t b_wpub = up(Fp * K * p->M * sizeof(float2));
     const size_t b_flags = up(16 * sizeof(unsigned));
     const size_t b_stamps = up((size_t)kResidentStampIters * kResidentStamps * sizeof(unsigned long long));
-    const size_t total = b_parts + b_psum + b_vpart + b_rsum + b_wpub + b_flags + b_stamps;
+    const size_t b_what = up((size_t)p->F * NA * sizeof(float2)), b_what64 = up((size_t)p->F * NA * sizeof(double2));
+    const size_t total = b_parts + b_psum + b_vpart + b_rsum + b_wpub + b_flags + b_stamps + b_what + b_what64;
     HIP_TRY(hipMalloc(&p->res_block, total));
     HIP_TRY(hipMemsetAsync(p->res_block, 0, total, p->stream));
     char* c = static_cast<char*>(p->res_block);
@@ -400,6 +405,10 @@ int resident_alloc(oiva_plan* p) {
     p->res_flags = reinterpret_cast<unsigned*>(c);
     c += b_flags;
     p->res_stamps = reinterpret_cast<unsigned long long*>(c);
+    c += b_stamps;
+    p->res_what = reinterpret_cast<float2*>(c);
+    c += b_what;
+    p->res_what64 = reinterpret_cast<double2*>(c);
     p->res_block_bytes = total;
     p->res_epoch = 0;
     return OIVA_OK;
@@ -416,6 +425,8 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     a.X = p->X;
     a.What = p->What;
     a.What64 = p->upd_f64() ? p->What64 : nullptr;
+    a.What_out = p->res_what;
+    a.What64_out = p->upd_f64() ? p->res_what64 : nullptr;
     a.what64_valid = p->what64_valid ? 1 : 0;
     a.Cx = p->Cx;
     a.parts = p->res_parts;
@@ -443,10 +454,12 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     a.g = g;
     a.n_iter = n;
     a.epoch0 = p->res_epoch;
-    a.timeout_ticks = (long long)(p->res_timeout_ms > 0 ? p->res_timeout_ms : 2000) * 100000;   // 100 MHz clock
+    a.timeout_ticks = (long long)(p->res_timeout_ms > 0 ? p->res_timeout_ms : (p->res_world > 1 && !p->res_loopback ? 2000 : 250)) * 100000;   // 100 MHz clock; an iteration takes tens of microseconds (other ranks may start late: 2 s)
     a.stall_block = p->res_stall;
+    a.stall_iter = p->res_stall_iter;
     a.rank = p->res_rank;
     a.world = p->res_world;
+    a.loopback = p->res_loopback ? 1 : 0;
     for (int r = 0; r < OIVA_XCHG_MAX_RANKS; ++r) a.gath[r] = reinterpret_cast<float*>(p->res_gath[r]);
     HIP_TRY(launch_resident(p->stream, a, p->M, p->K, p->upd_f64(), p->cov_f64()));
     p->res_launches++;
@@ -454,7 +467,8 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     unsigned code = 0;
     HIP_TRY(hipMemcpy(&code, a.ctrl, sizeof(code), hipMemcpyDeviceToHost));
     if (code != 0) {
-        // some wait ran into its time-out (workgroups not co-resident, or the test hook): W_hat was not written back.
+        // some wait ran into its time-out (workgroups not co-resident, or the test hook): whatever the workgroups that did
+        // finish wrote went to the staging copy, W_hat itself is untouched.
         // Clear the flags, start the epochs over and stay on the four-launch path from here on.
         HIP_TRY(hipMemset(p->res_block, 0, p->res_block_bytes));
         p->res_epoch = 0;
@@ -467,6 +481,10 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
                                         "): a rank did not deliver its parts in time; W_hat of this rank is unchanged");
         return OIVA_OK;
     }
+    // nobody gave up: the staged W_hat becomes the state (stream-ordered; every reader of What synchronises with the stream)
+    const size_t nW = (size_t)p->F * p->M * p->M;
+    HIP_TRY(hipMemcpyAsync(p->What, p->res_what, nW * sizeof(float2), hipMemcpyDeviceToDevice, p->stream));
+    if (a.What64_out) HIP_TRY(hipMemcpyAsync(p->What64, p->res_what64, nW * sizeof(double2), hipMemcpyDeviceToDevice, p->stream));
     p->res_epoch += (unsigned)n;
     p->res_stamped = (a.stamps && !a.stamp_all) ? n : 0;
     p->what64_valid = a.What64 != nullptr;      // the float32 update leaves the complex128 copy behind
@@ -674,6 +692,7 @@ int oiva_plan_destroy(oiva_plan* p) {
         if (b) (void)hipFree(b);
     for (void* b : p->og_bufs)
         if (b) (void)hipFree(b);
+    if (p->res_loop_buf) (void)hipFree(p->res_loop_buf);
     for (auto& ev : p->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
@@ -1177,8 +1196,42 @@ int oiva_plan_set_resident_splits(oiva_plan* p, int nsplit) {
     return OIVA_OK;
 }
 
+int oiva_plan_resident_loopback(oiva_plan* p, int world) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(world >= 0 && world <= OIVA_XCHG_MAX_RANKS, OIVA_ERR_ARG, "bad number of ranks");
+    NEED(!p->res_on, OIVA_ERR_STATE, "switch the resident iteration off before changing its exchange");
+    DeviceGuard guard(p->device);
+    if (p->res_loop_buf) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipFree(p->res_loop_buf));
+        p->res_loop_buf = nullptr;
+    }
+    p->res_loopback = false;
+    p->res_world = 1;
+    p->res_rank = 0;
+    for (auto& g : p->res_gath) g = nullptr;
+    if (world <= 1) return OIVA_OK;
+    NEED(p->res_ok, OIVA_ERR_ARG, "shape does not qualify for the X-resident iteration");
+    NEED(p->F == p->F_total, OIVA_ERR_STATE, "loop-back plays the other ranks with zeros: the plan must own all bins");
+    // the gather buffer of the multi-GPU exchange, same kind of memory (fine-grained, system-scope atomics), but nobody else
+    // maps it: [2 (epoch parity)][world][NS * TW][K] floats
+    const size_t bytes = (size_t)2 * world * p->rg.NS * p->rg.TW * p->K * sizeof(float);
+    HIP_TRY(hipExtMallocWithFlags((void**)&p->res_loop_buf, bytes, hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemset(p->res_loop_buf, 0, bytes));
+    for (int r = 0; r < world; ++r) p->res_gath[r] = p->res_loop_buf;
+    p->res_world = world;
+    p->res_loopback = true;
+    if (p->res_block) {                        // epochs restart with the fresh buffer
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipMemset(p->res_block, 0, p->res_block_bytes));
+        p->res_epoch = 0;
+    }
+    return OIVA_OK;
+}
+
 int oiva_plan_resident_connect(oiva_plan* p, oiva_xchg* x) {
     NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(!p->res_loopback, OIVA_ERR_STATE, "the plan runs the loop-back exchange (oiva_plan_resident_loopback(p, 0) switches it off)");
     if (!x) {                                  // back to a single rank
         p->res_world = 1;
         p->res_rank = 0;
@@ -1244,6 +1297,15 @@ int oiva_plan_resident_debug(oiva_plan* p, int timeout_ms, int stall_block) {
     NEED(p, OIVA_ERR_ARG, "null plan");
     p->res_timeout_ms = timeout_ms;
     p->res_stall = stall_block;
+    p->res_stall_iter = 0;
+    return OIVA_OK;
+}
+
+int oiva_plan_resident_debug_from(oiva_plan* p, int timeout_ms, int stall_block, int first_stalled_iteration) {
+    NEED(p && first_stalled_iteration >= 0, OIVA_ERR_ARG, "bad arguments");
+    p->res_timeout_ms = timeout_ms;
+    p->res_stall = stall_block;
+    p->res_stall_iter = first_stalled_iteration;
     return OIVA_OK;
 }
 

@@ -24,8 +24,10 @@ constexpr int kResidentLdsXBytes = 128 << 10;   // LDS given to X (of 160 KB; th
 
 struct ResidentArgs {
     const float2* X;        // (T, F, M)
-    float2* What;           // (F, M, M) complex64, in/out
-    double2* What64;        // complex128 copy kept by the float64 update (in/out) or nullptr
+    const float2* What;     // (F, M, M) complex64, the state the launch starts from
+    const double2* What64;  // complex128 copy kept by the float64 update, or nullptr
+    float2* What_out;       // staging copies the final state is written to; the host moves them into What / What64 when
+    double2* What64_out;    //   the launch finished without any workgroup giving up
     int what64_valid;       // the complex128 copy holds the current state
     const double* Cx;       // [F][M*M] packed Hermitian, / T
     // exchange buffers in this GPU's memory; every word of them is one agent-scope atomic access that carries its
@@ -40,6 +42,7 @@ struct ResidentArgs {
     // memory, [2 (epoch parity)][world][NS * TW][K] sums of the ranks' parts; every rank must run the same NS x TW
     float* gath[OIVA_XCHG_MAX_RANKS];
     int rank, world;
+    int loopback;           // world > 1 on ONE GPU: the leader stores the sums of all `world` slots (its own + zeros) into its own buffer
     unsigned long long* stamps;   // [n_iter][kResidentStamps] 100 MHz timestamps of workgroup 0 (stamp_all: [workgroup][n_iter][..]), or nullptr
     int stamp_all;          // every workgroup records its timestamps (tools/exp_resident_trace.py)
     int T, F, F_total, model;
@@ -47,7 +50,8 @@ struct ResidentArgs {
     int n_iter;
     unsigned epoch0;        // epochs epoch0 + 1 ... epoch0 + n_iter
     long long timeout_ticks;   // 100 MHz ticks a wait may take before the launch gives up
-    int stall_block;        // test hook: this workgroup never publishes (-1: none)
+    int stall_block;        // test hook: this workgroup never publishes (-1: none) ...
+    int stall_iter;         // ... from this iteration of the launch on
 };
 constexpr int kResidentStamps = 10;
 

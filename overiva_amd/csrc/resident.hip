@@ -32,7 +32,7 @@ bool resident_geometry(int T, int F, int M, int K, int n_cu, int ns_req, Residen
     g.JR = g.J > jl_max ? kResidentRegFrames : 0;
     const int jl = g.J - g.JR;
     g.lds_bytes = jl * (M / 2) * kBlock * 16 + kResidentMaxTW * K * 8 /* weights: float, or double (float64 covariance) */ +
-                  16 * (kBlock + 1) * 4 + kWaves * 8 + 16;
+                  16 * (kBlock + 1) * 4 + kWaves * 8 + 16 + kResidentMaxTW * K * 4 /* the activations r, for the floor */;
     *out = g;
     return true;
 }

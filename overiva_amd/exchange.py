@@ -14,7 +14,9 @@ release it once every rank has pushed; a wait that does not return within 5 s is
 back to the collective, on every rank alike (rank 0's choice of transport is broadcast, the verdicts are gathered), if
 anything is off.  A platform on which peer mappings or peer atomics do not work thus costs a warning, not a wrong result
 or a hang.  ``HSA_ENABLE_IPC_MODE_LEGACY=0`` must be in the environment before the process's first GPU call (this
-platform's driver exports device memory through dmabuf only); ``overiva_amd._lib`` sets it at import unless it is set.
+platform's driver exports device memory through dmabuf only): launchers export it for their ranks
+(``bench.py --gpus N``), and ``_lib.require_dmabuf_ipc`` sets it -- or warns that it is too late -- when a multi-process
+exchange is created; importing the package no longer changes the environment.
 """
 import ctypes as C
 import os
@@ -46,6 +48,8 @@ class PushExchange:
     name = "push"
 
     def __init__(self, device, rank, world, part_ptr, part_bytes, stream_handle):
+        if world > 1:
+            _lib.require_dmabuf_ipc("push exchange between processes")
         self.lib = _lib.load()
         self.rank, self.world = rank, world
         self.part_ptr, self.part_bytes, self.stream = int(part_ptr), int(part_bytes), int(stream_handle)

@@ -193,6 +193,11 @@ def overiva(
         solver.close()
 
 
+# (device, T, F, M, K) whose X-resident launch gave up in this process (its workgroups were not all co-resident: a shared or
+# CU-masked GPU): later calls of the same shape go straight to the four-launch path instead of waiting for the time-out again
+_resident_gave_up = set()
+
+
 class _SingleDevice:
     """all bins on one GPU"""
 
@@ -210,7 +215,9 @@ class _SingleDevice:
             self.plan.use_graph(True)
         # the loop body as one persistent launch with X on chip wherever the shape qualifies (csrc/resident_kernel.inc; the
         # float64 covariance of `precise` exists there for 4 channels); $OIVA_RESIDENT=0 keeps the four-launch path
-        if (precision != "precise" or M == 4) and os.environ.get("OIVA_RESIDENT", "1") != "0" and self.plan.resident_info()["qualifies"]:
+        self.key = (get_device(), T, F, M, K)
+        if ((precision != "precise" or M == 4) and os.environ.get("OIVA_RESIDENT", "1") != "0" and self.key not in _resident_gave_up
+                and self.plan.resident_info()["qualifies"]):
             self.plan.set_resident(True)
 
     def set_x(self, X):
@@ -241,6 +248,8 @@ class _SingleDevice:
         global _last_info
         if getattr(self.plan, "h", None):
             info = self.plan.resident_info()
+            if info["fallbacks"]:
+                _resident_gave_up.add(self.key)
             _last_info = {"precision": self.precision, "sharded": False, "resident_launches": info["launches"],
                           "resident_fallbacks": info["fallbacks"], "resident_give_up_code": info["last_give_up_code"]}
         self.plan.close()

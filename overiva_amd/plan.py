@@ -273,8 +273,15 @@ class Plan:
         _lib.check(self.lib.oiva_plan_resident_trace(self.h, 1 if enable else 0, _lib.ptr(out), C.byref(nw), C.byref(ni)))
         return out
 
-    def resident_debug(self, timeout_ms=0, stall_block=-1):
-        _lib.check(self.lib.oiva_plan_resident_debug(self.h, int(timeout_ms), int(stall_block)))
+    def resident_debug(self, timeout_ms=0, stall_block=-1, from_iteration=0):
+        """test hooks: time-out of a wait, and a workgroup that stops publishing from an iteration of the launch on"""
+        _lib.check(self.lib.oiva_plan_resident_debug_from(self.h, int(timeout_ms), int(stall_block), int(from_iteration)))
+
+    def resident_loopback(self, world=8):
+        """one GPU plays all ``world`` ranks of the kernel's multi-GPU exchange against itself (leader gather, ``world`` slot
+        stores, rank-order sum; the other ranks' sums are exact zeros, so the result is that of one rank); 0 switches it off.
+        Call it while resident is off."""
+        _lib.check(self.lib.oiva_plan_resident_loopback(self.h, int(world)))
 
     # -- test-only stage access -----------------------------------------------------------------
     def t_set_rinv(self, rinv):

@@ -129,13 +129,16 @@ class HipEngine:
             self.plan.set_resident_splits(ns)
             info = self.plan.resident_info()
             mine = (bool(info["qualifies"]), info["frame_splits"], info["frames_per_split"])
-        except ValueError as e:
-            mine = (False, 0, 0)
+        except Exception:      # (any failure of a plan call on one rank must reach the others through the next exchange,
+            mine = (False, 0, 0)   #  never escape between two collectives)
         dist.all_gather_object(alls, mine, group=group)
         if not all(a[0] for a in alls) or len({a[1:] for a in alls}) != 1:
             return f"the ranks found no common frame-split geometry: {alls}"
         if world == 1:
-            self.plan.set_resident(True)
+            try:
+                self.plan.set_resident(True)
+            except Exception as e:
+                return f"{type(e).__name__}: {e}"
             return None
         from .exchange import PushExchange
 
@@ -167,8 +170,21 @@ class HipEngine:
             if x is not None:
                 x.close()
             return "; ".join(f"rank {r}: {v[1]}" for r, v in enumerate(vs) if not v[0])
+        # switching it on allocates the kernel's exchange buffers: a failure on one rank is agreed on like the others
+        try:
+            self.plan.set_resident(True)
+            ok, why = True, ""
+        except Exception as e:
+            ok, why = False, f"{type(e).__name__}: {e}"
+        dist.all_gather_object(vs, (ok, why), group=group)
+        if not all(v[0] for v in vs):
+            for undo in (lambda: self.plan.set_resident(False), lambda: self.plan.resident_connect(None), x.close):
+                try:
+                    undo()
+                except Exception:
+                    pass
+            return "; ".join(f"rank {r}: {v[1]}" for r, v in enumerate(vs) if not v[0])
         self.resident_xchg = x
-        self.plan.set_resident(True)
         return None
 
     def iterate_resident(self, n):
@@ -240,8 +256,11 @@ class BinShardedSolver:
         dist.broadcast_object_list(choice, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         want = choice[0]
         self.resident, self.resident_refused = False, None
-        if want == "resident" and hasattr(self.engine, "setup_resident") and precision != "precise":
-            self.resident_refused = self.engine.setup_resident(dist, group, self.rank, self.world)
+        if want == "resident" and hasattr(self.engine, "setup_resident"):
+            if precision == "precise":      # (the kernel's float64 covariance exists for 4 channels on ONE rank only so far)
+                self.resident_refused = "precise arithmetic (float64 covariance sums) runs the collective path when sharded"
+            else:
+                self.resident_refused = self.engine.setup_resident(dist, group, self.rank, self.world)
             self.resident = self.resident_refused is None
         if hasattr(self.engine, "plan"):
             from .exchange import make_exchange

@@ -185,6 +185,82 @@ def test_resident_gives_up_and_falls_back(oa):
         assert np.all(np.isfinite(p.get_w()))
 
 
+@pytest.mark.parametrize("shape,mode", [((300, 64, 4, 2), "mixed"), ((700, 96, 8, 2), "fast"), ((120, 700, 4, 2), "mixed")])
+def test_give_up_in_the_last_iteration_changes_nothing(oa, shape, mode):
+    """a time-out that first strikes in the LAST iteration of a launch: most workgroups have finished all their iterations by
+    then and have written their final W_hat -- to the staging copy, which the host moves into place only when nobody gave up.
+    The call must leave W_hat as it was and run all its iterations on the four-launch path: same bits as that path alone
+    (a write-back from inside the kernel would leave the finished bins with twice the iterations)"""
+    T, F, M, K = shape
+    X = orc.synth_mixture(T, F, M, K, seed=4)
+    W4, Y4, _ = _run(oa, X, K, "laplace", mode, 6, False)
+    for stall_from in (5, 3):
+        with oa.Plan(T, F, M, K, "laplace") as p:
+            p.set_precision(mode)
+            p.set_x(X)
+            p.covariance()
+            p.set_w(None)
+            p.set_resident(True)
+            p.resident_debug(timeout_ms=20, stall_block=1, from_iteration=stall_from)
+            p.iterate(6)
+            info = p.resident_info()
+            assert info["fallbacks"] == 1 and info["enabled"] == 0 and info["last_give_up_code"] != 0
+            assert np.array_equal(p.get_w(np.complex128), W4) and np.array_equal(p.demix(False), Y4)
+
+
+@pytest.mark.parametrize("shape", [(4000, 256, 8, 2), (1000, 513, 4, 2), (700, 96, 8, 1), (300, 64, 4, 2)])
+@pytest.mark.parametrize("world", [8, 2])
+def test_loopback_world_runs_the_multi_gpu_exchange_on_one_gpu(oa, shape, world):
+    """the multi-GPU code path of the kernel (per frame split a leader gathers the rank's parts and stores the sums of all
+    `world` slots into the gather buffer, every workgroup polls its words of all slots and adds them in rank order) with
+    the one GPU playing every rank: the phantom ranks' sums are exact zeros, so the result is the single-rank one -- to the
+    mantissa bit the epoch tag takes from the stored sums"""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F, M, seed=8)
+    for model in ("laplace", "gauss"):
+        W1, Y1, _ = _run(oa, X, K, model, "mixed", 7, True, chunks=[3, 4])
+        with oa.Plan(T, F, M, K, model) as p:
+            p.set_precision("mixed")
+            p.set_x(X)
+            p.covariance()
+            p.set_w(None)
+            p.resident_loopback(world)
+            p.set_resident(True)
+            p.iterate(3)
+            p.iterate(4)
+            info = p.resident_info()
+            W, Y = p.get_w(np.complex128), p.demix(False)
+            assert info["fallbacks"] == 0 and info["launches"] == 2
+            # and off again: the plain single-rank kernel
+            p.set_resident(False)
+            p.resident_loopback(0)
+            p.set_resident(True)
+            p.iterate(1)
+            assert p.resident_info()["fallbacks"] == 0 and np.all(np.isfinite(p.get_w()))
+        eW, eY = orc.rel_err(W, W1), orc.rel_err(Y, Y1)
+        print(f"\n[loop-back world {world}] {shape} {model}: W {eW:.1e} Y {eY:.1e} vs the single-rank kernel")
+        assert eW < 1e-6 and eY < 1e-6
+
+
+def test_loopback_gives_up_like_a_missing_rank(oa):
+    """a leader that never stores its slots = a rank whose parts do not arrive: the launch gives up and reports it (a plan
+    with world > 1 does not fall back silently -- the other ranks' state is unknown)"""
+    T, F, M, K = 300, 64, 4, 2
+    X = orc.synth_iid(T, F, M, seed=8)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision("mixed")
+        p.set_x(X)
+        p.covariance()
+        p.set_w(None)
+        p.resident_loopback(8)
+        p.set_resident(True)
+        W0 = p.get_w(np.complex128)
+        p.resident_debug(timeout_ms=20, stall_block=0)
+        with pytest.raises(RuntimeError):
+            p.iterate(3)
+        assert np.array_equal(p.get_w(np.complex128), W0)
+
+
 def test_two_hop_exchange_gives_up_too(oa):
     """the same with 44 bin groups (the reduce-scatter / all-gather exchange of the powers has its own waits): a workgroup
     that never publishes its share of the column's sums stalls every workgroup of the column; the launch gives up, changes
