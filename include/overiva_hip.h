@@ -263,7 +263,7 @@ int oiva_plan_resident_debug_from(oiva_plan *p, int timeout_ms, int stall_block,
 int oiva_plan_resident_loopback(oiva_plan *p, int world);
 /* Diagnostics: with enable != 0 the next resident launches (of at most 64 iterations) record the timestamps of EVERY
  * workgroup; stamps_host (NULL: just switch) receives [n_wg][n_iter][OIVA_RESIDENT_STAMPS] 100 MHz ticks of the last one. */
-#define OIVA_RESIDENT_STAMPS 10
+#define OIVA_RESIDENT_STAMPS 16
 int oiva_plan_resident_trace(oiva_plan *p, int enable, unsigned long long *stamps_host, int *n_wg, int *n_iter);
 /* Bins sharded over the GPUs of a node: give the plan of a shard a connected oiva_xchg (below) whose slot is
  * frame_splits * frames_per_split * K * 4 bytes; the resident kernel then exchanges the ranks' partial source powers

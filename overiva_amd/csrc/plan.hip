@@ -113,8 +113,9 @@ struct oiva_plan {
     double* res_rsum = nullptr;
     float2* res_wpub = nullptr;
     unsigned* res_flags = nullptr; // ctrl words ([0] give-up code)
-    float2* res_what = nullptr;    // staging copies of the final W_hat of a launch (moved into What / What64 when nobody gave up)
-    double2* res_what64 = nullptr;
+    float2* res_what = nullptr;    // second copies of W_hat / its complex128 form: a launch writes its final state there, and the
+    double2* res_what64 = nullptr; //   plan swaps them with What / What64 when nobody gave up (own allocations)
+    unsigned* res_code_host = nullptr;   // pinned: the give-up code of a launch, copied behind it on the stream
     unsigned long long* res_stamps = nullptr;
     size_t res_block_bytes = 0;
     unsigned res_epoch = 0;
@@ -387,8 +388,10 @@ int resident_alloc(oiva_plan* p) {
     const size_t b_wpub = up(Fp * K * p->M * sizeof(float2));
     const size_t b_flags = up(16 * sizeof(unsigned));
     const size_t b_stamps = up((size_t)kResidentStampIters * kResidentStamps * sizeof(unsigned long long));
-    const size_t b_what = up((size_t)p->F * NA * sizeof(float2)), b_what64 = up((size_t)p->F * NA * sizeof(double2));
-    const size_t total = b_parts + b_psum + b_vpart + b_rsum + b_wpub + b_flags + b_stamps + b_what + b_what64;
+    const size_t total = b_parts + b_psum + b_vpart + b_rsum + b_wpub + b_flags + b_stamps;
+    if (!p->res_what) HIP_TRY(hipMalloc(&p->res_what, (size_t)p->F * NA * sizeof(float2)));
+    if (!p->res_what64) HIP_TRY(hipMalloc(&p->res_what64, (size_t)p->F * NA * sizeof(double2)));
+    if (!p->res_code_host) HIP_TRY(hipHostMalloc((void**)&p->res_code_host, sizeof(unsigned), hipHostMallocDefault));
     HIP_TRY(hipMalloc(&p->res_block, total));
     HIP_TRY(hipMemsetAsync(p->res_block, 0, total, p->stream));
     char* c = static_cast<char*>(p->res_block);
@@ -405,10 +408,6 @@ int resident_alloc(oiva_plan* p) {
     p->res_flags = reinterpret_cast<unsigned*>(c);
     c += b_flags;
     p->res_stamps = reinterpret_cast<unsigned long long*>(c);
-    c += b_stamps;
-    p->res_what = reinterpret_cast<float2*>(c);
-    c += b_what;
-    p->res_what64 = reinterpret_cast<double2*>(c);
     p->res_block_bytes = total;
     p->res_epoch = 0;
     return OIVA_OK;
@@ -463,9 +462,9 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     for (int r = 0; r < OIVA_XCHG_MAX_RANKS; ++r) a.gath[r] = reinterpret_cast<float*>(p->res_gath[r]);
     HIP_TRY(launch_resident(p->stream, a, p->M, p->K, p->upd_f64(), p->cov_f64()));
     p->res_launches++;
+    HIP_TRY(hipMemcpyAsync(p->res_code_host, a.ctrl, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));   // (pinned: one wait for both)
     HIP_TRY(hipStreamSynchronize(p->stream));
-    unsigned code = 0;
-    HIP_TRY(hipMemcpy(&code, a.ctrl, sizeof(code), hipMemcpyDeviceToHost));
+    const unsigned code = *p->res_code_host;
     if (code != 0) {
         // some wait ran into its time-out (workgroups not co-resident, or the test hook): whatever the workgroups that did
         // finish wrote went to the staging copy, W_hat itself is untouched.
@@ -481,10 +480,16 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
                                         "): a rank did not deliver its parts in time; W_hat of this rank is unchanged");
         return OIVA_OK;
     }
-    // nobody gave up: the staged W_hat becomes the state (stream-ordered; every reader of What synchronises with the stream)
-    const size_t nW = (size_t)p->F * p->M * p->M;
-    HIP_TRY(hipMemcpyAsync(p->What, p->res_what, nW * sizeof(float2), hipMemcpyDeviceToDevice, p->stream));
-    if (a.What64_out) HIP_TRY(hipMemcpyAsync(p->What64, p->res_what64, nW * sizeof(double2), hipMemcpyDeviceToDevice, p->stream));
+    // nobody gave up: the staged W_hat becomes the state -- the buffers change places (captured graphs of the four-launch path
+    // hold the old addresses: dropped, they are rebuilt if that path is ever used)
+    if (p->graph_exec || p->graph_batch_exec || p->og_graph) {
+        int rcg = drop_graph(p);
+        if (rcg) return rcg;
+    }
+    std::swap(p->What, p->res_what);
+    if (a.What64_out) std::swap(p->What64, p->res_what64);
+    p->og.What = p->What;
+    p->og.What64 = p->What64;
     p->res_epoch += (unsigned)n;
     p->res_stamped = (a.stamps && !a.stamp_all) ? n : 0;
     p->what64_valid = a.What64 != nullptr;      // the float32 update leaves the complex128 copy behind
@@ -686,7 +691,8 @@ int oiva_plan_destroy(oiva_plan* p) {
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->graph_batch_exec) (void)hipGraphExecDestroy(p->graph_batch_exec);
     if (p->og_graph) (void)hipGraphExecDestroy(p->og_graph);
-    void* bufs[] = {p->X_owned, p->X_pad, p->What, p->What64, p->Cx,        p->Vpart,    p->Ppart, p->Plocal, p->res_block, p->res_trace_buf,
+    if (p->res_code_host) (void)hipHostFree(p->res_code_host);
+    void* bufs[] = {p->X_owned, p->X_pad, p->What, p->What64, p->Cx,        p->Vpart,    p->Ppart, p->Plocal, p->res_block, p->res_trace_buf, p->res_what, p->res_what64,
                     p->R,       p->wscale, p->Spart, p->Y,      p->scratch_c, p->scratch_p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);

@@ -53,7 +53,7 @@ struct ResidentArgs {
     int stall_block;        // test hook: this workgroup never publishes (-1: none) ...
     int stall_iter;         // ... from this iteration of the launch on
 };
-constexpr int kResidentStamps = 10;
+constexpr int kResidentStamps = 16;     // 0..8 phase boundaries, 9 payload passes of the parts hop, 10..15 sub-steps of the update (diagnostics)
 
 // true when the shape can run resident on a chip of n_cu compute units (fills g)
 // ns_req > 0 asks for that many frame splits (at most what the chip holds); the result may have fewer when TW rounds up

@@ -264,17 +264,23 @@ struct Sq {
 // update_bg_kernel (kernels_update.hip).  Lane (i, j) of the bin's MP x MP group holds element [i][j] of
 // B = W_hat^H (in/out), C = Cx, V[s] = V_s (identity outside M x M).
 // ---------------------------------------------------------------------------------------------
-template <int MP, typename R, int K>
-__device__ __forceinline__ void bg_chain(const Sq<MP, R>& sq, Cx<R>& B, const Cx<R>& C, const Cx<R> (&V)[K], int M) {
+struct NoMark {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// The part of the chain that needs W_hat^H and Cx only (not the covariances): T = W^H Cx on rows < K, and the transpose of B.
+template <int MP, typename R>
+__device__ __forceinline__ void bg_pre(const Sq<MP, R>& sq, const Cx<R>& B, const Cx<R>& C, int M, Cx<R>& Tm, Cx<R>& Bt) {
+    Tm = sq.matmul(B, C, M);        // rows < K: W^H Cx (rows >= K unused)
+    Bt = sq.transp(B);              // lane (i, j): B[j][i]
+}
+// The chain proper, given V_s, their inverses and bg_pre's results.
+// (mark(n): optional time stamps of the caller, n = 2 + s after source s)
+template <int MP, typename R, int K, typename MARK = NoMark>
+__device__ __forceinline__ void bg_core(const Sq<MP, R>& sq, Cx<R>& B, const Cx<R>& C, const Cx<R> (&V)[K], const Cx<R> (&Vinv)[K], Cx<R> Tm,
+                                        Cx<R> Bt, int M, MARK mark = MARK()) {
     static_assert(K == 1 || K == 2, "closed-form K x K solves");
     const int i = sq.i, j = sq.j;
     const Cx<R> zero = {R(0), R(0)};
-    Cx<R> Vinv[K];
-#pragma unroll
-    for (int s = 0; s < K; ++s) Vinv[s] = sq.herm_inverse(V[s], M);
-
-    Cx<R> Tm = sq.matmul(B, C, M);        // rows < K: W^H Cx (rows >= K unused)
-    Cx<R> Bt = sq.transp(B);              // lane (i, j): B[j][i]
 #pragma unroll
     for (int s = 0; s < K; ++s) {
         // Q = B_tt + B_tb B_bt on lanes i, j < K
@@ -337,7 +343,19 @@ __device__ __forceinline__ void bg_chain(const Sq<MP, R>& sq, Cx<R>& B, const Cx
         const Cx<R> Jt = sq.transp(Jn);
         if (j < K && i >= K && i < M) B = {Jt.re, -Jt.im};
         Bt = sq.transp(B);
+        mark(2 + s);
     }
+}
+
+// everything in one call (the stand-alone update kernels)
+template <int MP, typename R, int K>
+__device__ __forceinline__ void bg_chain(const Sq<MP, R>& sq, Cx<R>& B, const Cx<R>& C, const Cx<R> (&V)[K], int M) {
+    Cx<R> Vinv[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) Vinv[s] = sq.herm_inverse(V[s], M);
+    Cx<R> Tm, Bt;
+    bg_pre<MP, R>(sq, B, C, M, Tm, Bt);
+    bg_core<MP, R, K>(sq, B, C, V, Vinv, Tm, Bt, M);
 }
 
 }  // namespace oiva

@@ -264,12 +264,12 @@ class Plan:
 
     def resident_trace(self, enable=True, fetch=False):
         """diagnostics: record every workgroup's timestamps in the next launches (<= 64 iterations); with ``fetch`` returns the
-        last launch's (n_wg, n_iter, 10) array of 100 MHz ticks"""
+        last launch's (n_wg, n_iter, 16) array of 100 MHz ticks"""
         nw, ni = C.c_int(), C.c_int()
         _lib.check(self.lib.oiva_plan_resident_trace(self.h, 1 if enable else 0, None, C.byref(nw), C.byref(ni)))
         if not fetch or ni.value == 0:
             return None
-        out = np.zeros((nw.value, ni.value, 10), np.uint64)
+        out = np.zeros((nw.value, ni.value, 16), np.uint64)
         _lib.check(self.lib.oiva_plan_resident_trace(self.h, 1 if enable else 0, _lib.ptr(out), C.byref(nw), C.byref(ni)))
         return out
 
