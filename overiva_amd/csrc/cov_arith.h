@@ -83,6 +83,11 @@ __device__ __forceinline__ v2f pk_fma_w0(v2f w, v2f p, v2f c) {         // c + w
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(p), "v"(c));
     return r;
 }
+__device__ __forceinline__ v2f pk_fma_wy_rot(v2f w, v2f x, v2f c) {     // (c.x - w.y * x.y, c.y + w.y * x.x): c + i w.y x
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(w), "v"(x), "v"(c));
+    return r;
+}
 __device__ __forceinline__ v2f pk_fma_w1(v2f w, v2f p, v2f c) {         // c + w.y * p
     v2f r;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(w), "v"(p), "v"(c));

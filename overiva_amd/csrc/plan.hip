@@ -384,7 +384,7 @@ int resident_alloc(oiva_plan* p) {
     const size_t b_parts = up((size_t)2 * g.NB * g.NS * g.TW * K * sizeof(float));
     const size_t b_psum = up((size_t)2 * g.NS * g.TW * K * sizeof(float));
     const size_t b_vpart = up(((size_t)g.NS * Fp * K * NA + 2) * sizeof(double));
-    const size_t b_rsum = up((size_t)g.NB * g.NS * K * sizeof(double));
+    const size_t b_rsum = up((size_t)g.NB * ((g.NS * K + 1) & ~(size_t)1) * sizeof(double) + 16);      // rows of an even number of words
     const size_t b_wpub = up(Fp * K * p->M * sizeof(float2));
     const size_t b_flags = up(16 * sizeof(unsigned));
     const size_t b_stamps = up((size_t)kResidentStampIters * kResidentStamps * sizeof(unsigned long long));

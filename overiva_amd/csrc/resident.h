@@ -35,7 +35,7 @@ struct ResidentArgs {
     float* parts;           // [2 (epoch parity)][NB][NS * TW][K] partial source powers
     float* psum;            // [2 (epoch parity)][NS * TW][K] their sums over the bin groups (two-hop exchange, many bin groups)
     double* vpart;          // [NS][NB * 16][K][M*M] packed partial covariances
-    double* rsum;           // [NB][NS][K] sum of the activations r over the split's frames
+    double* rsum;           // [NB][(NS K + 1) & ~1] sum of the activations r over the split's frames, word c K + k of row g
     float2* wpub;           // [NB * 16][K][M] conj of the demixing vectors, for the power phase
     unsigned* ctrl;         // [0] give-up code (0 = fine)
     // bins sharded over `world` GPUs (world == 1: unused): gath[r] = rank r's gather buffer as mapped here, fine-grained

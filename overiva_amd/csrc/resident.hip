@@ -25,6 +25,7 @@ bool resident_geometry(int T, int F, int M, int K, int n_cu, int ns_req, Residen
     g.NS = (T + g.TW - 1) / g.TW;
     g.J = g.TW / 16;
     if (g.J > j_max) return false;                           // does not fit on chip
+    // (+ 4 KB of static LDS in the kernel: the row's sums of r as fetched by each wave)
     // every bin of a group needs an update slot on the workgroups of its row: bin b -> workgroup b % NS, slot b / NS;
     // a workgroup has 4 waves x (64 / M^2) slots
     const int slots = 4 * (64 / (M * M));
