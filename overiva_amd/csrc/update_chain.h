@@ -264,87 +264,92 @@ struct Sq {
 // update_bg_kernel (kernels_update.hip).  Lane (i, j) of the bin's MP x MP group holds element [i][j] of
 // B = W_hat^H (in/out), C = Cx, V[s] = V_s (identity outside M x M).
 // ---------------------------------------------------------------------------------------------
-struct NoMark {
-    __device__ __forceinline__ void operator()(int) const {}
-};
 // The part of the chain that needs W_hat^H and Cx only (not the covariances): T = W^H Cx on rows < K, and the transpose of B.
 template <int MP, typename R>
 __device__ __forceinline__ void bg_pre(const Sq<MP, R>& sq, const Cx<R>& B, const Cx<R>& C, int M, Cx<R>& Tm, Cx<R>& Bt) {
     Tm = sq.matmul(B, C, M);        // rows < K: W^H Cx (rows >= K unused)
     Bt = sq.transp(B);              // lane (i, j): B[j][i]
 }
-// The chain proper, given V_s, their inverses and bg_pre's results.
-// (mark(n): optional time stamps of the caller, n = 2 + s after source s)
-template <int MP, typename R, int K, typename MARK = NoMark>
-__device__ __forceinline__ void bg_core(const Sq<MP, R>& sq, Cx<R>& B, const Cx<R>& C, const Cx<R> (&V)[K], const Cx<R> (&Vinv)[K], Cx<R> Tm,
-                                        Cx<R> Bt, int M, MARK mark = MARK()) {
+// One source of the chain proper (S = its index), given V_S, its inverse and the running T = W^H Cx and B^T: the IP1 solve +
+// normalisation of w_S (overiva.py:181-186) and the update of J from the orthogonality constraint (:189-190).
+template <int MP, typename R, int K, int S>
+__device__ __forceinline__ void bg_source(const Sq<MP, R>& sq, Cx<R>& B, const Cx<R>& C, const Cx<R>& Vs, const Cx<R>& Vinvs, Cx<R>& Tm, Cx<R>& Bt,
+                                          int M) {
     static_assert(K == 1 || K == 2, "closed-form K x K solves");
+    constexpr int s = S;
     const int i = sq.i, j = sq.j;
     const Cx<R> zero = {R(0), R(0)};
-#pragma unroll
-    for (int s = 0; s < K; ++s) {
-        // Q = B_tt + B_tb B_bt on lanes i, j < K
-        Cx<R> Q = B;
-        static_for<MP>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            if (m >= K && m < M) cfma(Q, sq.template rowb_c<m>(B), sq.colb(B, m));
-        });
-        // u_top = Q^-1 e_s
-        Cx<R> u0, u1 = zero;
-        if constexpr (K == 1) {
-            u0 = cinv(sq.template at_c<0, 0>(Q));
-        } else {
-            const Cx<R> q00 = sq.template at_c<0, 0>(Q), q01 = sq.template at_c<0, 1>(Q), q10 = sq.template at_c<1, 0>(Q),
-                        q11 = sq.template at_c<1, 1>(Q);
-            Cx<R> det = cmul(q00, q11);
-            cfms(det, q01, q10);
-            const Cx<R> idet = cinv(det);
-            u0 = s == 0 ? cmul(q11, idet) : cmul(Cx<R>{-q01.re, -q01.im}, idet);
-            u1 = s == 0 ? cmul(Cx<R>{-q10.re, -q10.im}, idet) : cmul(q00, idet);
-        }
-        // u, one entry per column: u_j = u_top[j] (j < K) | sum_m B[j][m] u_top[m] (K <= j < M)
-        Cx<R> ub = cmul(sq.colb(Bt, 0), u0);
-        if constexpr (K == 2) cfma(ub, sq.colb(Bt, 1), u1);
-        Cx<R> uj = j == 0 ? u0 : ((K == 2 && j == 1) ? u1 : ub);
-        if (j >= M) uj = zero;
-        // w = V^-1 u (one entry per row), then its copy per column
-        Cx<R> wi = sq.rowsum(cmul(Vinv[s], uj));
-        Cx<R> wj = sq.transp(wi);
-        // d = w^H V w, overiva.py:185
-        const Cx<R> vw = sq.rowsum(cmul(V[s], wj));
-        const R d = sq.allsum(j == 0 && i < M ? wi.re * vw.re + wi.im * vw.im : R(0));
-        const R sc = fast_rsqrt(d);
-        wi.re *= sc;
-        wi.im *= sc;
-        wj.re *= sc;
-        wj.im *= sc;
-        if (i == s && j < M) B = {wj.re, -wj.im};
-        // J from the orthogonality constraint, overiva.py:189-190 -> :96-98; row s of W^H Cx = sum_i conj(w_i) Cx[i][:]
-        Cx<R> t = cmul(Cx<R>{wi.re, -wi.im}, C);
-        t.re = sq.colsum(t.re);
-        t.im = sq.colsum(t.im);
-        if (i == s) Tm = t;
-        Cx<R> Jn;                          // lanes i < K, j >= K: J[i][j - K]
-        if constexpr (K == 1) {
-            Jn = cmul(sq.colb(Tm, 0), cinv(sq.template at_c<0, 0>(Tm)));
-        } else {
-            const Cx<R> t00 = sq.template at_c<0, 0>(Tm), t01 = sq.template at_c<0, 1>(Tm), t10 = sq.template at_c<1, 0>(Tm),
-                        t11 = sq.template at_c<1, 1>(Tm);
-            const Cx<R> r0 = sq.colb(Tm, 0), r1 = sq.colb(Tm, 1);        // Tm[0][j], Tm[1][j]
-            Cx<R> det = cmul(t00, t11);
-            cfms(det, t01, t10);
-            const Cx<R> idet = cinv(det);
-            Cx<R> n0 = cmul(t11, r0), n1 = cmul(t00, r1);
-            cfms(n0, t01, r1);
-            cfms(n1, t10, r0);
-            Jn = cmul(i == 0 ? n0 : n1, idet);
-        }
-        // W_hat[m][i] = J[m][i - K]  ->  (W_hat^H)[i][m] = conj, for K <= i < M, m = j < K
-        const Cx<R> Jt = sq.transp(Jn);
-        if (j < K && i >= K && i < M) B = {Jt.re, -Jt.im};
-        Bt = sq.transp(B);
-        mark(2 + s);
+    // Q = B_tt + B_tb B_bt on lanes i, j < K
+    Cx<R> Q = B;
+    static_for<MP>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if (m >= K && m < M) cfma(Q, sq.template rowb_c<m>(B), sq.colb(B, m));
+    });
+    // u_top = Q^-1 e_s
+    Cx<R> u0, u1 = zero;
+    if constexpr (K == 1) {
+        u0 = cinv(sq.template at_c<0, 0>(Q));
+    } else {
+        const Cx<R> q00 = sq.template at_c<0, 0>(Q), q01 = sq.template at_c<0, 1>(Q), q10 = sq.template at_c<1, 0>(Q),
+                    q11 = sq.template at_c<1, 1>(Q);
+        Cx<R> det = cmul(q00, q11);
+        cfms(det, q01, q10);
+        const Cx<R> idet = cinv(det);
+        u0 = s == 0 ? cmul(q11, idet) : cmul(Cx<R>{-q01.re, -q01.im}, idet);
+        u1 = s == 0 ? cmul(Cx<R>{-q10.re, -q10.im}, idet) : cmul(q00, idet);
     }
+    // u, one entry per column: u_j = u_top[j] (j < K) | sum_m B[j][m] u_top[m] (K <= j < M)
+    Cx<R> ub = cmul(sq.colb(Bt, 0), u0);
+    if constexpr (K == 2) cfma(ub, sq.colb(Bt, 1), u1);
+    // (component-wise selects: a select of an (re, im) pair may be compiled into a two-slot stack array indexed by the lane)
+    const bool j0 = j == 0, j1 = K == 2 && j == 1;
+    Cx<R> uj = {j0 ? u0.re : (j1 ? u1.re : ub.re), j0 ? u0.im : (j1 ? u1.im : ub.im)};
+    if (j >= M) uj = zero;
+    // w = V^-1 u (one entry per row), then its copy per column
+    Cx<R> wi = sq.rowsum(cmul(Vinvs, uj));
+    Cx<R> wj = sq.transp(wi);
+    // d = w^H V w, overiva.py:185
+    const Cx<R> vw = sq.rowsum(cmul(Vs, wj));
+    const R d = sq.allsum(j == 0 && i < M ? wi.re * vw.re + wi.im * vw.im : R(0));
+    const R sc = fast_rsqrt(d);
+    wi.re *= sc;
+    wi.im *= sc;
+    wj.re *= sc;
+    wj.im *= sc;
+    if (i == s && j < M) B = {wj.re, -wj.im};
+    // J from the orthogonality constraint, overiva.py:189-190 -> :96-98; row s of W^H Cx = sum_i conj(w_i) Cx[i][:]
+    Cx<R> t = cmul(Cx<R>{wi.re, -wi.im}, C);
+    t.re = sq.colsum(t.re);
+    t.im = sq.colsum(t.im);
+    if (i == s) Tm = t;
+    Cx<R> Jn;                          // lanes i < K, j >= K: J[i][j - K]
+    if constexpr (K == 1) {
+        Jn = cmul(sq.colb(Tm, 0), cinv(sq.template at_c<0, 0>(Tm)));
+    } else {
+        const Cx<R> t00 = sq.template at_c<0, 0>(Tm), t01 = sq.template at_c<0, 1>(Tm), t10 = sq.template at_c<1, 0>(Tm),
+                    t11 = sq.template at_c<1, 1>(Tm);
+        const Cx<R> r0 = sq.colb(Tm, 0), r1 = sq.colb(Tm, 1);        // Tm[0][j], Tm[1][j]
+        Cx<R> det = cmul(t00, t11);
+        cfms(det, t01, t10);
+        const Cx<R> idet = cinv(det);
+        Cx<R> n0 = cmul(t11, r0), n1 = cmul(t00, r1);
+        cfms(n0, t01, r1);
+        cfms(n1, t10, r0);
+        const bool i0 = i == 0;
+        Jn = cmul(Cx<R>{i0 ? n0.re : n1.re, i0 ? n0.im : n1.im}, idet);
+    }
+    // W_hat[m][i] = J[m][i - K]  ->  (W_hat^H)[i][m] = conj, for K <= i < M, m = j < K
+    const Cx<R> Jt = sq.transp(Jn);
+    if (j < K && i >= K && i < M) B = {Jt.re, -Jt.im};
+    Bt = sq.transp(B);
+}
+
+// The chain proper: the sources one after the other.
+template <int MP, typename R, int K>
+__device__ __forceinline__ void bg_core(const Sq<MP, R>& sq, Cx<R>& B, const Cx<R>& C, const Cx<R> (&V)[K], const Cx<R> (&Vinv)[K], Cx<R> Tm,
+                                        Cx<R> Bt, int M) {
+    bg_source<MP, R, K, 0>(sq, B, C, V[0], Vinv[0], Tm, Bt, M);
+    if constexpr (K == 2) bg_source<MP, R, K, 1>(sq, B, C, V[1], Vinv[1], Tm, Bt, M);
 }
 
 // everything in one call (the stand-alone update kernels)
