@@ -18,6 +18,7 @@ struct ResidentGeom {
     int lds_bytes = 0;
 };
 constexpr int kResidentRegFrames = 8;
+constexpr int kResidentF64ReduceFrames = 4;  // up to this many frames per lane the covariance sums are added over all 16 frame phases in float64
 constexpr int kResidentTwoHopGroups = 40;    // from this many bin groups on, the powers are summed in two hops (reduce-scatter, all-gather)
 constexpr int kResidentMaxTW = 256;          // one thread per frame of the split in the activation phase
 constexpr int kResidentLdsXBytes = 128 << 10;   // LDS given to X (of 160 KB; the rest is reduction scratch and tables)
