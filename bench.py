@@ -49,6 +49,8 @@ CONFIGS = {
     "cfg5": dict(T=4000, F=2048, M=16, K=16, name="determined AuxIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[4])"),
     "cfg2": dict(T=1000, F=513, M=4, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64 (BASELINE.json configs[1])"),
     "shard8": dict(T=4000, F=256, M=8, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64: one rank's shard of the headline shape at 8 GPUs (BASELINE.json configs[3])"),
+    "shard2": dict(T=4000, F=1024, M=8, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64: one rank's shard of the headline shape at 2 GPUs"),
+    "shard4": dict(T=4000, F=512, M=8, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, complex64: one rank's shard of the headline shape at 4 GPUs"),
     # BASELINE configs[0] is the reference's own one-shot call (overiva_oneshot.py -a overiva -m 4 -s 2: STFT of 4096-point frames
     # = 2049 bins x ~160 frames x 4 mics, complex128): the iteration of that shape, in the arithmetic of complex128 input
     "cfg0": dict(T=160, F=2049, M=4, K=2, name="OverIVA {F} bins x {T} frames x {M} mics / {K} src, laplace, the shape and arithmetic (complex128 input) of the reference's one-shot call (BASELINE.json configs[0])"),
@@ -364,6 +366,26 @@ def _secondary_config(torch, oa, dev, name, args):
                                                      "order -- what every rank of `bench.py --gpus 8` runs, minus the flight over xGMI")
             except Exception as e:
                 out["resident_loopback8"] = {"error": f"{type(e).__name__}: {e}"}
+    if name in ("shard2", "shard4"):
+        # what every rank of `bench.py --gpus 2 / 4` runs: the four-launch iteration replayed from graphs with the exchange of the
+        # ranks' partial powers inside the activation kernel -- here in loop-back (this GPU plays all ranks: everything but the
+        # flight of the peer stores over xGMI)
+        world = 2 if name == "shard2" else 4
+        try:
+            plan = _make_plan(oa, X, shape, mode, False)
+            plan.fused_loopback(world)
+            plan.use_graph(True)
+            dtf, totf, stagesf, moref = _time_plan(plan, args, repeats=args.repeats)
+            plan.close()
+            out["fused_loopback"] = {"world": world, "value": args.steps / dtf, "unit": "iterations/s", "ms_per_step": dtf / args.steps * 1e3,
+                                     **_rates(args.steps, [dtf] + moref), "stage_ms_per_step": {k: v / args.steps for k, v in stagesf.items()},
+                                     "what": "four kernels per iteration replayed from hipGraphs, no host call and no collective in the loop: the "
+                                             "activation kernel adds the rank's parts, stores the sums into the other ranks' slots, polls its own "
+                                             f"buffer and adds the {world} ranks' sums in rank order"}
+            out["value"], out["path"] = out["fused_loopback"]["value"], f"four launches per iteration (hipGraph replay) with the in-kernel exchange, loop-back world {world}"
+            best = out["fused_loopback"]
+        except Exception as e:
+            out["fused_loopback"] = {"error": f"{type(e).__name__}: {e}"}
     out.update({k: best[k] for k in ("value_median", "value_min", "value_max", "repeats")})
     out["unit"] = "iterations/s"
     return out
@@ -427,7 +449,7 @@ def run_single(args):
     torch.cuda.empty_cache()
     if not args.no_configs and args.config == "headline":
         out["configs"] = {}
-        for name in ("cfg0", "cfg2", "shard8", "cfg5", "m16k2"):
+        for name in ("cfg0", "cfg2", "shard2", "shard4", "shard8", "cfg5", "m16k2"):
             try:
                 out["configs"][name] = _secondary_config(torch, oa, dev, name, args)
                 out["config"][f"iterations_per_s_{name}"] = out["configs"][name]["value"]
@@ -499,7 +521,11 @@ def run_sharded(args):
         resident_refused = None
         if want_resident:
             resident_refused = eng.setup_resident(dist, None, rank, world) if args.precision != "precise" else "precise arithmetic"
-        xchg = make_exchange(eng, dist, None, rank, world, p_local, p_all, prefer="collective" if want_resident else args.exchange)
+        # shards that do not fit on chip (2 and 4 GPUs): the exchange inside the activation kernel of the four-launch iteration
+        want_fused = args.exchange == "fused" or (args.exchange == "auto" and resident_refused is not None)
+        fused_refused = eng.setup_fused(dist, None, rank, world) if want_fused else None
+        fused = want_fused and fused_refused is None
+        xchg = make_exchange(eng, dist, None, rank, world, p_local, p_all, prefer="collective" if (want_resident or want_fused) else args.exchange)
         nparts = world * ppr
 
         def step():
@@ -533,12 +559,45 @@ def run_sharded(args):
             eng.set_w(None)
             stream.synchronize()
         if want_resident and resident_refused is not None and rank == 0:
-            print(f"[bench] X-resident exchange not used: {resident_refused}; collective", file=sys.stderr)
+            print(f"[bench] X-resident exchange not used: {resident_refused}", file=sys.stderr)
         resident = want_resident and resident_refused is None
+        if fused:
+            # the same validation for the exchange inside the activation kernel: one iteration through it against one through the
+            # collective, from the same start, on every rank (rank-by-rank association of the sum: agreement to rounding)
+            why = None
+            try:
+                step()                  # (power pass + all-gather + update on the gathered parts: the plain activation kernel)
+                stream.synchronize()
+                w_coll = eng.get_w()
+                eng.set_w(None)
+                eng.plan.iterate(1)
+                eng.plan.sync()
+                w_f = eng.get_w()
+                err = float(np.linalg.norm(w_f - w_coll) / max(np.linalg.norm(w_coll), 1e-30))
+                if not err < 1e-4:
+                    why = f"one iteration differs from the collective path by {err:.1e}"
+            except Exception as e:
+                why = f"{type(e).__name__}: {e}"
+            notes = [None] * world
+            dist.all_gather_object(notes, why)
+            if any(n is not None for n in notes):
+                fused_refused = "validation failed: " + "; ".join(f"rank {r}: {n}" for r, n in enumerate(notes) if n is not None)
+                fused = False
+                try:
+                    eng.plan.fused_connect(None)
+                except Exception:
+                    pass
+            eng.set_w(None)
+            stream.synchronize()
+        if want_fused and not fused and rank == 0:
+            print(f"[bench] exchange inside the activation kernel not used: {fused_refused}; collective", file=sys.stderr)
 
         graph = None
-        if resident:
-            # one persistent launch per call: W warm-up iterations, then exactly K timed ones
+        if resident or fused:
+            # resident: one persistent launch per call; fused: captured graphs of four kernels per iteration, no host call in
+            # between.  W warm-up iterations, then exactly K timed ones
+            if fused:
+                eng.plan.use_graph(True)
             eng.plan.iterate(args.steps)
             eng.plan.iterate(args.warmup)
             stream.synchronize()
@@ -549,9 +608,14 @@ def run_sharded(args):
             stream.synchronize()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            phases, _ = eng.plan.resident_phases()
-            breakdown = {"resident_phase_us_workgroup0": phases}
-            cov_ms = None
+            if resident:
+                phases, _ = eng.plan.resident_phases()
+                breakdown = {"resident_phase_us_workgroup0": phases}
+                cov_ms = None
+            else:
+                breakdown = {}
+                cov_ms = eng.plan.t_time_stage("weighted_cov", 20)
+                stream.synchronize()
         else:
             for _ in range(args.warmup):
                 step()
@@ -633,9 +697,16 @@ def run_sharded(args):
         roof["per"] = "GPU"
         roof.setdefault("traffic", None)
         out["roofline"] = roof
+        if fused:
+            out["config"]["graph"] = True
+            out["config"]["parallelism"] = (f"bins sharded over {world} GPU(s); four kernels per iteration replayed from hipGraphs, the partial source "
+                                            "powers exchanged inside the activation kernel by peer stores over xGMI (no collective, no host call in the loop)")
     out["cpu_baseline"] = None      # reported at N = 1 only
-    out["ranks"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "exchange": "resident" if resident else exchange_name,
-                    "exchange_requested": args.exchange, "fallback": resident_refused or exchange_fallback,
+    out["ranks"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                    "exchange": "resident" if resident else ("fused" if fused else exchange_name),
+                    "exchange_requested": args.exchange,
+                    "fallback": None if (resident or fused) else (fused_refused or resident_refused or exchange_fallback),
+                    "resident_refused": resident_refused, "fused_refused": fused_refused,
                     "per_rank_stage_ms": gathered, "message_bytes_per_rank": int(p_local.numel() * 4)}
     dist.destroy_process_group()
     dog.cancel()
@@ -779,11 +850,12 @@ def main():
     ap.add_argument("--no-other-mode", action="store_true", help="do not also time the other arithmetic modes")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (exercises RCCL + graph capture on 1 GPU)")
-    ap.add_argument("--exchange", choices=["auto", "collective", "push", "resident"], default=os.environ.get("OIVA_EXCHANGE", "auto"),
+    ap.add_argument("--exchange", choices=["auto", "collective", "push", "resident", "fused"], default=os.environ.get("OIVA_EXCHANGE", "auto"),
                     help="exchange of the partial powers when sharded.  auto (default): inside the X-resident kernel where every "
-                         "rank's shard fits on chip (the headline shape at 8 GPUs) AND one iteration through it reproduces the "
-                         "collective path on this platform, else torch.distributed's collective (RCCL); collective; push: the "
-                         "library's push exchange (validated at start-up, falls back to the collective); resident: as auto")
+                         "rank's shard fits on chip (the headline shape at 8 GPUs), else inside the activation kernel of the "
+                         "four-launch iteration (2 and 4 GPUs) -- each only if one iteration through it reproduces the collective "
+                         "path on this platform --, else torch.distributed's collective (RCCL); collective; push: the library's "
+                         "push exchange (validated at start-up, falls back to the collective); resident / fused: only that one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the sharded path (nccl = RCCL; tests use gloo)")
     ap.add_argument("--single-device", action="store_true",
                     help="tests on a 1-GPU box: every rank uses GPU 0 (needs --backend gloo: RCCL refuses two ranks on one device)")

@@ -272,6 +272,23 @@ int oiva_plan_resident_trace(oiva_plan *p, int enable, unsigned long long *stamp
  * (F < F_total).  Every rank must call oiva_plan_iterate with the same counts.  A launch that gives up returns
  * OIVA_ERR_STATE (nothing written).  x = NULL disconnects. */
 int oiva_plan_resident_connect(oiva_plan *p, struct oiva_xchg *x);
+/*
+ * The same exchange for shards that do NOT fit on chip (2 and 4 GPUs at the headline shape), inside the four-launch
+ * iteration: give the plan a connected oiva_xchg whose slot is T * K * 8 bytes; the ACTIVATION kernel then adds its rank's
+ * 64-bin parts, stores the sum of every (frame, source) -- one 8-byte {value, epoch} word -- into its slot of every other
+ * rank's buffer (peer stores over xGMI), polls its own buffer for the other ranks' words and adds the ranks' sums in rank
+ * order (overiva.py:152-155; the same bits of r on every rank).  No collective, no stream wait, no host in the loop:
+ * oiva_plan_iterate works on a shard (F < F_total) and replays captured graphs of four kernels per iteration.  Every rank
+ * must run the same number of iterations.  A wait that gives up (default 2 s) is reported by the next oiva_plan_sync /
+ * oiva_plan_get_w (OIVA_ERR_STATE).  x = NULL disconnects.
+ *   oiva_plan_fused_loopback: world >= 2: ONE GPU runs that exchange against itself (own buffer, the other ranks' sums are
+ *                             zeros: the result is the single-GPU one up to the association of the sum); 0 / 1: off.
+ *   oiva_plan_fused_debug   : test hooks -- time-out of a wait in milliseconds (0: default); stall != 0: in loop-back the other
+ *                             ranks' words are never stored (a rank that does not deliver)
+ */
+int oiva_plan_fused_connect(oiva_plan *p, struct oiva_xchg *x);
+int oiva_plan_fused_loopback(oiva_plan *p, int world);
+int oiva_plan_fused_debug(oiva_plan *p, int timeout_ms, int stall);
 /* Number of frame splits of the resident grid (0: the library's choice).  The ranks of a sharded run must use one
  * geometry: they agree on the smallest count any of them chose (uneven shards).  Call it while resident is off. */
 int oiva_plan_set_resident_splits(oiva_plan *p, int nsplit);

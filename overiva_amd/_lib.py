@@ -79,6 +79,9 @@ SIGNATURES = {
     "oiva_plan_resident_debug": [_vp, _i, _i],
     "oiva_plan_resident_debug_from": [_vp, _i, _i, _i],
     "oiva_plan_resident_loopback": [_vp, _i],
+    "oiva_plan_fused_connect": [_vp, _vp],
+    "oiva_plan_fused_loopback": [_vp, _i],
+    "oiva_plan_fused_debug": [_vp, _i, _i],
     "oiva_plan_resident_connect": [_vp, _vp],
     "oiva_plan_resident_trace": [_vp, _i, _vp, C.POINTER(_i), C.POINTER(_i)],
     "oiva_plan_set_resident_splits": [_vp, _i],

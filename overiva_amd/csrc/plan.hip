@@ -128,6 +128,13 @@ struct oiva_plan {
     int res_trace_iters = 0;
     char* res_gath[OIVA_XCHG_MAX_RANKS] = {};   // every rank's gather buffer (bins sharded over GPUs), else unused
     int res_rank = 0, res_world = 1;
+    // exchange of the ranks' partial powers inside the activation kernel of the four-launch path (oiva_plan_fused_connect)
+    bool fx_on = false, fx_loopback = false;
+    char* fx_gath[OIVA_XCHG_MAX_RANKS] = {};
+    int fx_rank = 0, fx_world = 1;
+    char* fx_loop_buf = nullptr;                // loop-back: this plan's own gather buffer
+    unsigned* fx_state = nullptr;               // [0] give-up flag, [16 ...] one epoch counter per workgroup of the activation kernel
+    int fx_timeout_ms = 0, fx_stall = 0;
     hipGraphExec_t graph_exec = nullptr;        // one iteration
     hipGraphExec_t graph_batch_exec = nullptr;  // kGraphBatch iterations
     hipEvent_t ev[2] = {};
@@ -327,6 +334,14 @@ int stage_power(oiva_plan* p) {
     return OIVA_OK;
 }
 int stage_activation(oiva_plan* p, const float* parts, int nparts) {
+    if (p->fx_on && parts == p->Ppart) {
+        // bins sharded over GPUs, the ranks' sums exchanged by the activation kernel itself (no collective, no host in the loop)
+        HIP_TRY(launch_activation_xchg(p->stream, parts, nparts, p->fx_gath, p->fx_rank, p->fx_world, p->fx_loopback ? (p->fx_stall ? 2 : 1) : 0, p->fx_state + 16,
+                                       p->fx_state, (long long)(p->fx_timeout_ms > 0 ? p->fx_timeout_ms : 2000) * 100000, p->R, p->T, p->K,
+                                       p->model, p->F_total));
+        p->raw_weights = 0;
+        return OIVA_OK;
+    }
     HIP_TRY(launch_activation(p->stream, parts, nparts, p->R, p->T, p->K, p->model, p->F_total));
     p->raw_weights = 0;
     return OIVA_OK;
@@ -699,6 +714,8 @@ int oiva_plan_destroy(oiva_plan* p) {
     for (void* b : p->og_bufs)
         if (b) (void)hipFree(b);
     if (p->res_loop_buf) (void)hipFree(p->res_loop_buf);
+    if (p->fx_loop_buf) (void)hipFree(p->fx_loop_buf);
+    if (p->fx_state) (void)hipFree(p->fx_state);
     for (auto& ev : p->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
@@ -879,8 +896,9 @@ int oiva_plan_iterate(oiva_plan* p, int n) {
     int rc = check_ready(p);
     if (rc) return rc;
     NEED(n >= 0, OIVA_ERR_ARG, "negative iteration count");
-    NEED(p->F == p->F_total || resident_applies(p), OIVA_ERR_STATE,
-         "plan owns a bin shard: drive it with oiva_plan_power / all-gather / oiva_plan_update (or connect the X-resident exchange)");
+    NEED(p->F == p->F_total || resident_applies(p) || p->fx_on, OIVA_ERR_STATE,
+         "plan owns a bin shard: drive it with oiva_plan_power / all-gather / oiva_plan_update (or connect an in-kernel exchange: "
+         "oiva_plan_fused_connect, oiva_plan_resident_connect)");
     DeviceGuard guard(p->device);
     if (n == 0) return OIVA_OK;
     if (resident_applies(p)) {
@@ -986,6 +1004,8 @@ int oiva_plan_demix_c128(oiva_plan* p, void* Y_host, long long row_pitch_bytes, 
     return OIVA_OK;
 }
 
+static int check_fused(oiva_plan* p);
+
 int oiva_plan_get_w(oiva_plan* p, void* W_host, int f64) {
     NEED(p && W_host, OIVA_ERR_ARG, "null argument");
     NEED(p->have_w, OIVA_ERR_STATE, "demixing matrix not set");
@@ -1010,11 +1030,97 @@ int oiva_plan_get_w(oiva_plan* p, void* W_host, int f64) {
     return OIVA_OK;
 }
 
+// the in-kernel exchange of the four-launch path gave up waiting for a rank (recorded on the device, looked at here)
+static int check_fused(oiva_plan* p) {
+    if (!p->fx_state) return OIVA_OK;
+    unsigned code = 0;
+    HIP_TRY(hipMemcpy(&code, p->fx_state, sizeof(code), hipMemcpyDeviceToHost));
+    if (code != 0)
+        return fail(OIVA_ERR_STATE, "the exchange inside the activation kernel gave up waiting for a rank's partial powers (workgroup " +
+                                        std::to_string(code - 1) + "): the state of this plan is undefined");
+    return OIVA_OK;
+}
+
 int oiva_plan_sync(oiva_plan* p) {
     NEED(p, OIVA_ERR_ARG, "null plan");
     DeviceGuard guard(p->device);
     HIP_TRY(hipStreamSynchronize(p->stream));
+    return check_fused(p);
+}
+
+static int fused_setup(oiva_plan* p) {
+    const size_t words = 16 + (size_t)rsum_blocks(p->T) * p->K;
+    if (!p->fx_state) HIP_TRY(hipMalloc((void**)&p->fx_state, words * sizeof(unsigned)));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemset(p->fx_state, 0, words * sizeof(unsigned)));
+    return drop_graph(p);                       // captured graphs hold the other activation kernel
+}
+
+int oiva_plan_fused_connect(oiva_plan* p, oiva_xchg* x) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(!p->fx_loopback, OIVA_ERR_STATE, "the plan runs the loop-back exchange (oiva_plan_fused_loopback(p, 0) switches it off)");
+    DeviceGuard guard(p->device);
+    if (!x) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        p->fx_on = false;
+        p->fx_world = 1;
+        p->fx_rank = 0;
+        for (auto& g : p->fx_gath) g = nullptr;
+        return drop_graph(p);
+    }
+    char* peers[OIVA_XCHG_MAX_RANKS];
+    int rank = 0, world = 1;
+    size_t slot = 0;
+    NEED(xchg_peers(x, peers, &rank, &world, &slot) == 0, OIVA_ERR_STATE, "exchange not connected");
+    NEED(slot == (size_t)p->T * p->K * 8, OIVA_ERR_ARG, "exchange slot size must be T * K * 8 bytes (one {value, epoch} word per frame and source)");
+    int rc = fused_setup(p);
+    if (rc) return rc;
+    for (int r = 0; r < OIVA_XCHG_MAX_RANKS; ++r) p->fx_gath[r] = peers[r];
+    p->fx_rank = rank;
+    p->fx_world = world;
+    p->fx_on = true;
     return OIVA_OK;
+}
+
+int oiva_plan_fused_loopback(oiva_plan* p, int world) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(world >= 0 && world <= OIVA_XCHG_MAX_RANKS, OIVA_ERR_ARG, "bad number of ranks");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->fx_loop_buf) {
+        HIP_TRY(hipFree(p->fx_loop_buf));
+        p->fx_loop_buf = nullptr;
+    }
+    if (p->fx_loopback) {
+        p->fx_on = p->fx_loopback = false;
+        p->fx_world = 1;
+        for (auto& g : p->fx_gath) g = nullptr;
+        int rc = drop_graph(p);
+        if (rc) return rc;
+    }
+    if (world <= 1) return OIVA_OK;
+    NEED(!p->fx_on, OIVA_ERR_STATE, "the plan is connected to other ranks (oiva_plan_fused_connect(p, NULL) disconnects)");
+    NEED(p->F == p->F_total, OIVA_ERR_STATE, "loop-back plays the other ranks with zeros: the plan must own all bins");
+    const size_t bytes = (size_t)2 * world * p->T * p->K * 8;
+    HIP_TRY(hipExtMallocWithFlags((void**)&p->fx_loop_buf, bytes, hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemset(p->fx_loop_buf, 0, bytes));
+    int rc = fused_setup(p);
+    if (rc) return rc;
+    for (int r = 0; r < world; ++r) p->fx_gath[r] = p->fx_loop_buf;
+    p->fx_rank = 0;
+    p->fx_world = world;
+    p->fx_loopback = true;
+    p->fx_on = true;
+    return OIVA_OK;
+}
+
+int oiva_plan_fused_debug(oiva_plan* p, int timeout_ms, int stall) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    DeviceGuard guard(p->device);
+    p->fx_timeout_ms = timeout_ms;
+    p->fx_stall = stall;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return drop_graph(p);                       // (both are kernel arguments of captured launches)
 }
 
 int oiva_plan_iterate_timed(oiva_plan* p, int n, float* total_ms, float* per_kernel_ms) {
@@ -1141,7 +1247,7 @@ int oiva_plan_use_graph(oiva_plan* p, int enable) {
     DeviceGuard guard(p->device);
     p->use_graph = enable ? 1 : 0;
     if (!enable) return drop_graph(p);
-    if (p->have_x && p->have_cx && p->have_w && p->F == p->F_total) return build_graphs(p);
+    if (p->have_x && p->have_cx && p->have_w && (p->F == p->F_total || p->fx_on)) return build_graphs(p);
     return OIVA_OK;
 }
 

@@ -262,6 +262,19 @@ class Plan:
         rank's partial powers through; None disconnects"""
         _lib.check(self.lib.oiva_plan_resident_connect(self.h, xchg_handle))
 
+    def fused_connect(self, xchg_handle):
+        """bins sharded over GPUs and the shard does not fit on chip: the connected exchange (``exchange.PushExchange.h``, slot
+        = T * K * 8 bytes) through which the ACTIVATION kernel of the four-launch iteration exchanges the ranks' partial powers
+        itself; ``iterate`` then works on a shard, replaying captured graphs.  None disconnects."""
+        _lib.check(self.lib.oiva_plan_fused_connect(self.h, xchg_handle))
+
+    def fused_loopback(self, world=2):
+        """one GPU plays all ``world`` ranks of that exchange against itself (the other ranks' sums are zeros); 0 switches it off"""
+        _lib.check(self.lib.oiva_plan_fused_loopback(self.h, int(world)))
+
+    def fused_debug(self, timeout_ms=0, stall=False):
+        _lib.check(self.lib.oiva_plan_fused_debug(self.h, int(timeout_ms), 1 if stall else 0))
+
     def resident_trace(self, enable=True, fetch=False):
         """diagnostics: record every workgroup's timestamps in the next launches (<= 64 iterations); with ``fetch`` returns the
         last launch's (n_wg, n_iter, 16) array of 100 MHz ticks"""

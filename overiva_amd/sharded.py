@@ -22,9 +22,10 @@ def enable_bin_sharding(group=None, exchange=None):
     """Make ``overiva()`` shard bins over the ranks of ``group`` (default: the world group).
     Every rank must then call ``overiva()`` with the same arguments; every rank gets the full result.
     ``exchange``: "collective" (torch.distributed all-gather, the default), "push" (the library's own exchange,
-    validated against the collective before use; see exchange.py) or "resident" (the X-resident kernel with the exchange
-    of the partial powers inside it, where every rank's shard fits on chip: ``BinShardedSolver``); None reads
-    $OIVA_EXCHANGE."""
+    validated against the collective before use; see exchange.py), "resident" (the X-resident kernel with the exchange
+    of the partial powers inside it, where every rank's shard fits on chip: ``BinShardedSolver``) or "fused" (the
+    exchange inside the activation kernel of the four-launch iteration, any shard size, graphs replayed without the host);
+    None reads $OIVA_EXCHANGE."""
     import torch.distributed as dist
 
     if not dist.is_initialized():
@@ -190,6 +191,48 @@ class HipEngine:
     def iterate_resident(self, n):
         self.plan.iterate(n)
 
+    def setup_fused(self, dist, group, rank, world):
+        """The exchange of the ranks' partial powers inside the activation kernel of the four-launch iteration (shards that do
+        not fit on chip: 2 and 4 GPUs at the headline shape): no collective and no host in the loop, ``plan.iterate(n)``
+        replays captured graphs of four kernels.  The ranks map each other's gather buffers (``PushExchange``, slot = T K 8
+        bytes) and agree on the outcome.  Returns the reason it was NOT switched on, or None."""
+        from .exchange import PushExchange
+
+        x, ok, why, mineh = None, True, "", b"\0" * 64
+        try:
+            x = PushExchange(self.device.index, rank, world, 0, self.T * self.K * 8, self.stream.cuda_stream)
+            mineh = x.handle()
+        except Exception as e:
+            ok, why = False, f"{type(e).__name__}: {e}"
+        hs = [None] * world
+        dist.all_gather_object(hs, (ok, mineh, why), group=group)
+        if all(h[0] for h in hs):
+            try:
+                if world > 1:
+                    x.connect([h[1] for h in hs])
+                self.plan.fused_connect(x.h)
+                self.plan.use_graph(True)
+            except Exception as e:
+                ok, why = False, f"{type(e).__name__}: {e}"
+        else:
+            ok = False
+            why = why or "; ".join(f"rank {r}: {h[2]}" for r, h in enumerate(hs) if not h[0])
+        vs = [None] * world
+        dist.all_gather_object(vs, (ok, why), group=group)
+        if not all(v[0] for v in vs):
+            for undo in (lambda: self.plan.fused_connect(None), lambda: x.close()):
+                try:
+                    undo()
+                except Exception:
+                    pass
+            return "; ".join(f"rank {r}: {v[1]}" for r, v in enumerate(vs) if not v[0])
+        self.fused_xchg = x
+        return None
+
+    def iterate_fused(self, n):
+        self.plan.iterate(n)
+        self.plan.sync()
+
     def power(self):
         self.plan.power()
 
@@ -213,9 +256,10 @@ class HipEngine:
 
     def close(self):
         self.plan.close()
-        if getattr(self, "resident_xchg", None) is not None:
-            self.resident_xchg.close()
-            self.resident_xchg = None
+        for name in ("resident_xchg", "fused_xchg"):
+            if getattr(self, name, None) is not None:
+                getattr(self, name).close()
+                setattr(self, name, None)
 
 
 class BinShardedSolver:
@@ -262,11 +306,16 @@ class BinShardedSolver:
             else:
                 self.resident_refused = self.engine.setup_resident(dist, group, self.rank, self.world)
             self.resident = self.resident_refused is None
+        # "fused": the exchange inside the activation kernel of the four-launch iteration (any shard size)
+        self.fused, self.fused_refused = False, None
+        if want == "fused" and hasattr(self.engine, "setup_fused"):
+            self.fused_refused = self.engine.setup_fused(dist, group, self.rank, self.world)
+            self.fused = self.fused_refused is None
         if hasattr(self.engine, "plan"):
             from .exchange import make_exchange
 
             self.xchg = make_exchange(self.engine, dist, group, self.rank, self.world, self.p_local, self.p_all,
-                                      prefer="collective" if want == "resident" else want)
+                                      prefer="collective" if want in ("resident", "fused") else want)
         else:
             self.xchg = None
 
@@ -297,6 +346,21 @@ class BinShardedSolver:
             self.set_w(eig_init(self.get_cx(), self.K))
 
     def iterate(self, n):
+        if self.fused:
+            # every rank replays the same n iterations from captured graphs; a wait that gave up is reported by the sync:
+            # the ranks compare notes before anybody goes on
+            try:
+                with self.engine.stream_ctx():
+                    self.engine.iterate_fused(n)
+                mine = None
+            except RuntimeError as e:
+                mine = str(e)
+            notes = [None] * self.world
+            self.dist.all_gather_object(notes, mine, group=self.group)
+            if any(m is not None for m in notes):
+                raise RuntimeError("sharded iteration (exchange inside the activation kernel) failed: " +
+                                   "; ".join(f"rank {r}: {m}" for r, m in enumerate(notes) if m is not None))
+            return
         if self.resident:
             # every rank launches the same n iterations; a launch that gave up (a rank's parts did not arrive) leaves W
             # unchanged on that rank only, so the ranks compare notes before anybody goes on
@@ -343,7 +407,9 @@ class BinShardedSolver:
         _ov = sys.modules[__package__ + ".overiva"]      # (the package attribute `overiva` is the function, not the module)
         _ov._last_info = {"sharded": True, "world": self.world, "resident": getattr(self, "resident", False),
                           "resident_refused": getattr(self, "resident_refused", None),
-                          "exchange": "resident" if getattr(self, "resident", False) else getattr(self.xchg, "name", None)}
+                          "fused": getattr(self, "fused", False), "fused_refused": getattr(self, "fused_refused", None),
+                          "exchange": "resident" if getattr(self, "resident", False) else
+                          ("fused" if getattr(self, "fused", False) else getattr(self.xchg, "name", None))}
         if getattr(self, "xchg", None) is not None:
             self.engine.sync()
             self.xchg.close()

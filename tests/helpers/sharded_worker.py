@@ -44,7 +44,8 @@ def main():
     oa.disable_bin_sharding()
     if dist.get_rank() == 0:
         np.savez(out, Y=Y, W=W, cb=np.stack(seen), world=dist.get_world_size(), resident=bool(info.get("resident")),
-                 refused=str(info.get("resident_refused")), backend=dist.get_backend())
+                 refused=str(info.get("resident_refused") or info.get("fused_refused")), backend=dist.get_backend(),
+                 exchange=str(info.get("exchange")))
     dist.barrier()
     dist.destroy_process_group()
     torch.cuda.synchronize()

@@ -1,0 +1,123 @@
+"""The exchange of the ranks' partial source powers INSIDE the activation kernel of the four-launch iteration
+(csrc/kernels_misc.hip::activation_xchg_kernel, overiva.py:152-155 with the bins sharded over GPUs whose shards do not
+fit on chip: 2 and 4 GPUs at the headline shape): no collective, no host in the loop, graphs of four kernels replayed.
+One GPU here: the loop-back form (this GPU plays every rank, the other ranks' sums are exact zeros -- the result must be
+the single-GPU one BIT FOR BIT, eager and from graphs), a rank that does not deliver, and real processes sharing the GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import overiva_oracle as orc
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import overiva_amd
+    from overiva_amd import _lib
+
+    _lib.load()
+    return overiva_amd
+
+
+def _run(oa, X, K, model, mode, chunks, world=0, graph=False):
+    T, F, M = X.shape
+    with oa.Plan(T, F, M, K, model) as p:
+        p.set_precision(mode)
+        p.set_x(X)
+        p.covariance()
+        p.set_w(None)
+        if world:
+            p.fused_loopback(world)
+        if graph:
+            p.use_graph(True)
+        for n in chunks:
+            p.iterate(n)
+        p.sync()
+        return p.get_w(np.complex128), p.demix(False)
+
+
+@pytest.mark.parametrize("shape", [(4000, 512, 8, 2), (1000, 513, 4, 2), (300, 70, 6, 3), (257, 64, 16, 16), (200, 40, 8, 1)])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_loopback_is_bit_equal_to_one_gpu(oa, shape, world):
+    """this GPU as every rank: the rank's own parts are added in the order of the plain activation kernel and the other
+    ranks contribute exact zeros, so W and Y are those of the plain four-launch path bit for bit -- eager launches and
+    graph replay (the epoch is counted on the device), iterations in several calls, both models"""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F, M, seed=21)
+    for model in ("laplace", "gauss"):
+        W0, Y0 = _run(oa, X, K, model, "mixed", [3, 9, 1])
+        for graph in (False, True):
+            W, Y = _run(oa, X, K, model, "mixed", [3, 9, 1], world=world, graph=graph)
+            assert np.array_equal(W, W0) and np.array_equal(Y, Y0), (model, graph)
+
+
+def test_a_rank_that_does_not_deliver_is_reported(oa):
+    T, F, M, K = 300, 64, 4, 2
+    X = orc.synth_iid(T, F, M, seed=2)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_x(X)
+        p.covariance()
+        p.set_w(None)
+        p.fused_loopback(2)
+        p.iterate(2)
+        p.sync()
+        p.fused_debug(timeout_ms=20, stall=True)
+        p.iterate(1)
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            p.sync()
+
+
+def test_switching_the_exchange_off_restores_the_plain_path(oa):
+    T, F, M, K = 300, 64, 4, 2
+    X = orc.synth_iid(T, F, M, seed=2)
+    W0, _ = _run(oa, X, K, "laplace", "mixed", [4])
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision("mixed")
+        p.set_x(X)
+        p.covariance()
+        p.set_w(None)
+        p.use_graph(True)
+        p.fused_loopback(4)
+        p.iterate(2)
+        p.fused_loopback(0)
+        p.iterate(2)
+        assert np.array_equal(p.get_w(np.complex128), W0)
+
+
+def _workers(tmp_path, world, T, F, M, K, model, precision, n_iter, port):
+    out = str(tmp_path / f"fused_{world}.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "helpers", "sharded_worker.py"), out, str(T), str(F), str(M),
+           str(K), model, precision, str(n_iter), "fused", "eye", "gloo", "mixture"]
+    r = subprocess.run(cmd, cwd=REPO, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("world,F,model", [(2, 128, "laplace"), (3, 200, "gauss"), (4, 256, "laplace")])
+def test_processes_sharing_one_gpu(oa, tmp_path, world, F, model):
+    """real processes, one plan each on the box's one GPU, the exchange inside their activation kernels through IPC-mapped
+    fine-grained buffers (across GPUs the stores travel over xGMI): callbacks, projection back and the gathers of the sharded
+    driver around graph replays.  Against the four-launch path in one process: the sum over the bins is associated rank by
+    rank instead of part by part, so W and Y agree to rounding, not bit for bit."""
+    T, M, K, n_iter = 300, 4, 2, 12
+    got = _workers(tmp_path, world, T, F, M, K, model, "mixed", n_iter, 29700 + world)
+    assert int(got["world"]) == world and str(got["exchange"]) == "fused", (str(got["exchange"]), str(got["refused"]))
+    oa.set_precision("mixed")
+    os.environ["OIVA_RESIDENT"] = "0"
+    try:
+        X = orc.synth_mixture(T, F, M, K, seed=11)
+        seen = []
+        Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, model=model, return_filters=True, callback=lambda y: seen.append(y.copy()))
+    finally:
+        oa.set_precision("auto")
+        os.environ.pop("OIVA_RESIDENT", None)
+    eW, eY = orc.rel_err(got["W"], W), orc.rel_err(got["Y"], Y)
+    print(f"\n[fused, {world} processes] W {eW:.1e} Y {eY:.1e}")
+    assert eW < 2e-5 and eY < 2e-5 and got["cb"].shape == np.stack(seen).shape
