@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "liboveriva_hip.so")
+# ($OIVA_LIB: another build of the same library -- kernel variants under measurement, tools/build_variant.py)
+LIB_PATH = os.environ.get("OIVA_LIB") or os.path.join(_PKG, "liboveriva_hip.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NUMERIC = 0, -1, -2, -3, -4
 MODEL_IDS = {"laplace": 0, "gauss": 1}
