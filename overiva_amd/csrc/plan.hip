@@ -401,7 +401,7 @@ int resident_alloc(oiva_plan* p) {
     const size_t b_vpart = up(((size_t)g.NS * Fp * K * NA + 2) * sizeof(double));
     const size_t b_rsum = up((size_t)g.NB * ((g.NS * K + 1) & ~(size_t)1) * sizeof(double) + 16);      // rows of an even number of words
     const size_t b_wpub = up(Fp * K * p->M * sizeof(float2));
-    const size_t b_flags = up(16 * sizeof(unsigned));
+    const size_t b_flags = up((16 + (size_t)g.NB * g.NS) * sizeof(unsigned));      // ctrl words, then the XCD table
     const size_t b_stamps = up((size_t)kResidentStampIters * kResidentStamps * sizeof(unsigned long long));
     const size_t total = b_parts + b_psum + b_vpart + b_rsum + b_wpub + b_flags + b_stamps;
     if (!p->res_what) HIP_TRY(hipMalloc(&p->res_what, (size_t)p->F * NA * sizeof(float2)));
@@ -449,6 +449,7 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     a.rsum = p->res_rsum;
     a.wpub = p->res_wpub;
     a.ctrl = p->res_flags;
+    a.xcc_tab = p->res_flags + 16;
     a.stamps = n <= kResidentStampIters ? p->res_stamps : nullptr;
     a.stamp_all = 0;
     if (p->res_trace && n <= 64) {

@@ -39,6 +39,7 @@ struct ResidentArgs {
     double* rsum;           // [NB][(NS K + 1) & ~1] sum of the activations r over the split's frames, word c K + k of row g
     float2* wpub;           // [NB * 16][K][M] conj of the demixing vectors, for the power phase
     unsigned* ctrl;         // [0] give-up code (0 = fine)
+    unsigned* xcc_tab;      // [NB][NS] (launch tag << 8) | (XCD of the workgroup + 1): which rows sit on one XCD
     // bins sharded over `world` GPUs (world == 1: unused): gath[r] = rank r's gather buffer as mapped here, fine-grained
     // memory, [2 (epoch parity)][world][NS * TW][K] sums of the ranks' parts; every rank must run the same NS x TW
     float* gath[OIVA_XCHG_MAX_RANKS];
