@@ -100,7 +100,7 @@ def _workers(tmp_path, world, T, F, M, K, model, precision, n_iter, port):
     return np.load(out)
 
 
-@pytest.mark.parametrize("world,F,model", [(2, 128, "laplace"), (3, 200, "gauss"), (4, 256, "laplace")])
+@pytest.mark.parametrize("world,F,model", [(2, 128, "laplace"), (3, 200, "gauss"), (4, 256, "laplace"), (8, 512, "laplace")])
 def test_processes_sharing_one_gpu(oa, tmp_path, world, F, model):
     """real processes, one plan each on the box's one GPU, the exchange inside their activation kernels through IPC-mapped
     fine-grained buffers (across GPUs the stores travel over xGMI): callbacks, projection back and the gathers of the sharded

@@ -21,7 +21,7 @@ def _run(tmp_path, world, T, F, M, K, model, precision, n_iter, port, exchange="
            "--master-port", str(port), os.path.join(REPO, "tests", "helpers", "sharded_worker.py"), out, str(T), str(F), str(M),
            str(K), model, precision, str(n_iter), exchange, init, backend, data]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=180)
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return np.load(out)
 
@@ -112,6 +112,34 @@ def test_resident_shard_through_an_rccl_group(tmp_path):
     assert np.array_equal(got["W"], W) and np.array_equal(got["Y"], Y) and np.array_equal(got["cb"], np.stack(seen))
     _, Wr = orc.overiva_staged(X.astype(np.complex128), n_src=K, n_iter=n_iter, proj_back=False, return_filters=True)
     assert orc.rel_err(W, Wr) < 1e-5
+
+
+@pytest.mark.parametrize("world,F,T", [(8, 128, 300), (8, 512, 128)])
+def test_eight_resident_ranks_on_one_gpu(tmp_path, world, F, T):
+    """EIGHT real processes -- the world size of BASELINE configs[3] -- whose persistent kernels are resident side by side on
+    the box's one GPU (16 and 64 bins per rank: 10 and 32 workgroups each) and exchange their column sums through all eight
+    slots of every rank's IPC-mapped gather buffer, every workgroup adding the eight ranks' sums in rank order: the code path
+    of `bench.py --gpus 8`, minus the flight over xGMI.  Same result as the four-launch path in one process to rounding (the
+    sums cross the ranks as tagged words that give one mantissa bit to the epoch, so no grouping of the bins makes the two
+    bit-identical; the 64-bin case has the shard bounds on the 64-bin batches of the single-GPU sum)."""
+    import overiva_amd as oa
+    from oracle import overiva_oracle as orc
+
+    M, K, n_iter = 4, 2, 12
+    got = _run(tmp_path, world, T, F, M, K, "laplace", "mixed", n_iter, 29660 + F // 128, "resident")
+    assert int(got["world"]) == world and bool(got["resident"]), str(got["refused"])
+    oa.set_precision("mixed")
+    os.environ["OIVA_RESIDENT"] = "0"
+    try:
+        X = orc.synth_mixture(T, F, M, K, seed=11)
+        seen = []
+        Y, W = oa.overiva(X, n_src=K, n_iter=n_iter, proj_back=True, return_filters=True, callback=lambda y: seen.append(y.copy()))
+    finally:
+        oa.set_precision("auto")
+        os.environ.pop("OIVA_RESIDENT", None)
+    eW, eY = orc.rel_err(got["W"], W), orc.rel_err(got["Y"], Y)
+    print(f"\n[resident, {world} processes, {F} bins] W {eW:.1e} Y {eY:.1e}")
+    assert eW < 2e-5 and eY < 2e-5 and got["cb"].shape == np.stack(seen).shape
 
 
 @pytest.mark.parametrize("world,F", [(2, 128), (3, 192)])
