@@ -90,7 +90,7 @@ def measured_traffic(kernel_key):
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction; see
     profiles/r03_pmc_hbm_traffic.json).  PMC counters need rocprofv3 around the process, so they cannot
     be sampled from inside a plain bench run; None when the profile is absent."""
-    for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
         path = os.path.join(REPO, "profiles", name)
         try:
             with open(path) as f:

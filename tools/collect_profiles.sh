@@ -61,6 +61,13 @@ for c in "FETCH_SIZE" "WRITE_SIZE"; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_resident_cfg2/p$i" -o p -- python3 $ROOT/tools/resident_case.py 1000 513 4 2 50 > /dev/null 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_resident" -o s -- python3 $ROOT/tools/resident_case.py 4000 256 8 2 50 > "$OUT/resident_shard8.log" 2>&1
+# (round 4) the shard step at several launch lengths, single rank and loop-back world 8; the fixed cost of a launch; every
+# workgroup's phase boundaries; the 2- and 4-GPU shards through the exchange inside the activation kernel (loop-back)
+python3 $ROOT/tools/shard_step.py > "$OUT/shard_step.log" 2>&1
+python3 $ROOT/tools/launch_cost.py > "$OUT/launch_cost.log" 2>&1
+python3 $ROOT/tools/exp_resident_trace.py 4000 256 8 2 20 mixed > "$OUT/resident_trace_shard8.log" 2>&1
+python3 $ROOT/tools/exp_resident_trace.py 4000 256 8 2 20 mixed 8 > "$OUT/resident_trace_shard8_loopback8.log" 2>&1
+python3 $ROOT/tools/res_ab.py > "$OUT/resident_configs.log" 2>&1
 # keep what travels back small: drop the raw kernel traces of the --stats runs
 find "$OUT" -name "*_kernel_trace.csv" -path "*stats_*" -delete
 find "$OUT" -name "*_agent_info.csv" -delete
