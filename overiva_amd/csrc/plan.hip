@@ -243,6 +243,10 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         //  16.8.  On a long axis the floor of 128 stays: a 256-bin shard of 4000 frames takes 28 splits in 20.4 us, 32 splits
         //  -- exactly the chip's 512 workgroup slots, which the dispatcher does not fill evenly -- 26.3)
         nsplit = pick_splits(p->n_cu * bpc, g.nbg * nz, p->T, p->T >= 1024 ? 128 : 64);
+        // a grid that fills the chip's workgroup slots EXACTLY runs slower than one an eighth short of it (the dispatcher does
+        // not fill the CUs evenly): 512 bins x 4000 frames, 16 splits = 512 workgroups 31.4 us, 14 splits 29.5 us; 256 bins: 32
+        // splits 26.3 us, 28 splits 20.4 us
+        if (nsplit >= 12 && g.nbg * nz * nsplit >= p->n_cu * bpc) nsplit = nsplit * 7 / 8;
         // the update kernel adds the nsplit partials of every matrix element in one round of loads per 16 splits
         // (sum_vpart); more than 32 splits cost more there than the fuller grid saves here (measured on a
         // 256-bin shard: 16 splits 25.2 + 8.0 us, 28 splits 21.4 + 9.2 us, 42 splits 25.5 + 10.3 us)

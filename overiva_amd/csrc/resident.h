@@ -65,5 +65,7 @@ hipError_t launch_resident(hipStream_t s, const ResidentArgs& a, int M, int K, b
 // per-shape instantiations (kernels_resident_m4.hip, kernels_resident_m8.hip)
 hipError_t launch_resident_m4(hipStream_t s, const ResidentArgs& a, int K, bool update_f64, bool cov_f64);
 hipError_t launch_resident_m8(hipStream_t s, const ResidentArgs& a, int K, bool update_f64, bool cov_f64);
+hipError_t launch_resident_m6(hipStream_t s, const ResidentArgs& a, int K, bool update_f64, bool cov_f64);
+hipError_t launch_resident_m2(hipStream_t s, const ResidentArgs& a, int K, bool update_f64, bool cov_f64);
 
 }  // namespace oiva

@@ -102,6 +102,10 @@ BIG_CASES = [
     ("s", 150, 15, 13, 3),
     ("t", 144, 12, 15, 15),
     ("u", 133, 14, 11, 6),
+    # (round 4) 6 and 2 channels with 1-2 sources + background: the X-resident kernel beyond 4 / 8 channels
+    ("w", 160, 24, 6, 2),
+    ("x", 150, 40, 6, 1),
+    ("y", 176, 33, 2, 1),
 ]
 BIG_ITERS = (1, 5, 20)
 

@@ -18,7 +18,7 @@ STFT input; the distance is ||a-b||_F / ||b||_F.
   documented envelope of FAST_FLOORS reference floors -- an accuracy statement of that mode, not the parity claim.
 
 Every end-to-end comparison appends a row to $OIVA_PARITY_LOG (JSON lines) when that variable is set;
-profiles/r02_parity_errors.md is made from it.
+profiles/rNN_parity_errors.md is made from it (tools/parity_table.py).
 """
 import json
 import os

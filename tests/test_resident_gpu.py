@@ -44,7 +44,7 @@ def _qualifying():
     for path, gid in zip(golden_files(), golden_ids()):
         with np.load(path) as d:
             M, K = d["X"].shape[2], int(d["K"])
-        if M in (4, 8) and K in (1, 2) and K < M:
+        if M in (2, 4, 6, 8) and K in (1, 2) and K < M:
             out.append(pytest.param(path, id=gid))
     return out
 
@@ -79,7 +79,10 @@ def test_resident_matches_reference_fixtures(oa, path, model, mode):
 
 
 @pytest.mark.parametrize("shape", [(1000, 513, 4, 2), (4000, 256, 8, 2), (4000, 250, 8, 1), (3999, 256, 4, 2), (700, 96, 8, 2),
-                                   (160, 2049, 4, 2), (235, 2049, 4, 1), (200, 800, 8, 2), (120, 1000, 8, 1)])
+                                   (160, 2049, 4, 2), (235, 2049, 4, 1), (200, 800, 8, 2), (120, 1000, 8, 1),
+                                   # (round 4) 6 and 2 channels: the reference's sweep shapes (2049 bins x 160-235 frames), register
+                                   # frames at 6 channels, ragged bin groups
+                                   (235, 2049, 6, 2), (160, 2049, 6, 1), (235, 2049, 2, 1), (4000, 200, 6, 2), (500, 70, 2, 1)])
 @pytest.mark.parametrize("mode", ["fast", "mixed"])
 def test_resident_equals_four_launch_path(oa, shape, mode):
     """BASELINE configs[1], one rank's shard of the headline shape at 8 GPUs (full and ragged), 4 channels with 16 frames
@@ -283,7 +286,7 @@ def test_two_hop_exchange_gives_up_too(oa):
 
 
 def test_shapes_that_do_not_qualify(oa):
-    for shape in ((4000, 2048, 8, 2), (200, 40, 6, 2), (200, 40, 8, 8), (200, 40, 8, 3)):
+    for shape in ((4000, 2048, 8, 2), (200, 40, 7, 2), (200, 40, 8, 8), (200, 40, 8, 3), (200, 40, 6, 3), (200, 40, 2, 2)):
         T, F, M, K = shape
         with oa.Plan(T, F, M, K, "laplace") as p:
             assert p.resident_info()["qualifies"] == 0
