@@ -80,9 +80,10 @@ def test_resident_matches_reference_fixtures(oa, path, model, mode):
 
 @pytest.mark.parametrize("shape", [(1000, 513, 4, 2), (4000, 256, 8, 2), (4000, 250, 8, 1), (3999, 256, 4, 2), (700, 96, 8, 2),
                                    (160, 2049, 4, 2), (235, 2049, 4, 1), (200, 800, 8, 2), (120, 1000, 8, 1),
-                                   # (round 4) 6 and 2 channels: the reference's sweep shapes (2049 bins x 160-235 frames), register
-                                   # frames at 6 channels, ragged bin groups
-                                   (235, 2049, 6, 2), (160, 2049, 6, 1), (235, 2049, 2, 1), (4000, 200, 6, 2), (500, 70, 2, 1)])
+                                   # (round 4) 6 and 2 channels: 2 channels at the reference's 2049 bins (6 and 8 channels update one bin
+                                   # per wave, i.e. need >= 4 frame splits: at most 1024 bins), register frames at 6 channels, ragged
+                                   # bin groups
+                                   (235, 1024, 6, 2), (160, 1000, 6, 1), (235, 2049, 2, 1), (4000, 200, 6, 2), (500, 70, 2, 1)])
 @pytest.mark.parametrize("mode", ["fast", "mixed"])
 def test_resident_equals_four_launch_path(oa, shape, mode):
     """BASELINE configs[1], one rank's shard of the headline shape at 8 GPUs (full and ragged), 4 channels with 16 frames
