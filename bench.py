@@ -483,7 +483,7 @@ def run_sharded(args):
     import torch
     import torch.distributed as dist
 
-    from overiva_amd.sharded import HipEngine, shard_bounds
+    from overiva_amd.sharded import HipEngine, fused_blocks, shard_bounds
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
@@ -523,7 +523,7 @@ def run_sharded(args):
             resident_refused = eng.setup_resident(dist, None, rank, world) if args.precision != "precise" else "precise arithmetic"
         # shards that do not fit on chip (2 and 4 GPUs): the exchange inside the activation kernel of the four-launch iteration
         want_fused = args.exchange == "fused" or (args.exchange == "auto" and resident_refused is not None)
-        fused_refused = eng.setup_fused(dist, None, rank, world) if want_fused else None
+        fused_refused = eng.setup_fused(dist, None, rank, world, fused_blocks(b)) if want_fused else None
         fused = want_fused and fused_refused is None
         xchg = make_exchange(eng, dist, None, rank, world, p_local, p_all, prefer="collective" if (want_resident or want_fused) else args.exchange)
         nparts = world * ppr

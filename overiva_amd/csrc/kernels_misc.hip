@@ -9,10 +9,8 @@ namespace {
 
 // Source activation, reference overiva.py:152-155:
 //   R[t,k] = 2 sqrt(p) (laplace) | p / F_total (gauss), p = sum over parts in part order (bin batch, or rank then
-//   batch).  One thread per frame adds the parts strictly in order, so parts that are all zero (the padding that
-//   equalises the ranks' messages in a bin-sharded run) change nothing: a sharded run whose shard boundaries fall
-//   on 64-bin batches gets the same bits as the single-GPU run.  The loads of a group of 8 parts are issued
-//   together; the adds are sequential.  Each block (kBlock frames of one source) also leaves the float64 sum of its r per
+//   batch), associated in the canonical blocks described in the kernel: a sharded run with equal shards on 64-bin
+//   batches gets the same bits as the single-GPU run.  The loads of a group of 8 parts are issued together.  Each block (kBlock frames of one source) also leaves the float64 sum of its r per
 //   source behind R (rsum_offset_floats): the consumers derive gamma (overiva.py:158) from those few values
 //   (gamma_of) instead of re-reducing the T activations in every workgroup.
 __global__ __launch_bounds__(kBlock) void activation_kernel(const float* __restrict__ parts, int nparts,
@@ -25,25 +23,31 @@ __global__ __launch_bounds__(kBlock) void activation_kernel(const float* __restr
     float r = 0.f;
     if (t < T) {
         const size_t e = (size_t)t * K + k;
+        // Canonical order of the sum over the parts (all paths of the library, whatever the number of GPUs): the parts in
+        // blocks of ceil(nparts / 8) consecutive ones -- at most 8 blocks --, each block added sequentially, then the block
+        // sums sequentially.  A rank of a sharded run that holds whole blocks can send their sums instead of its parts and
+        // every rank still forms the SAME sum: the same bits of r at 1, 2, 4 and 8 GPUs (activation_xchg_kernel).  Up to 8
+        // parts the order is the plain sequential one.
+        const int bs = (nparts + kCanonBlocks - 1) / kCanonBlocks;
         float p = 0.f;
-        // the adds are sequential in part order whatever the grouping of the loads; 32 loads in flight = the 2048-bin
-        // single-GPU case in one memory round trip instead of four
-        int i = 0;
-        for (; i + 32 <= nparts; i += 32) {
-            float v[32];
+        for (int b0 = 0; b0 < nparts; b0 += bs) {
+            float pb = 0.f;
+            const int b1 = min(nparts, b0 + bs);
+            int i = b0;
+            for (; i + 8 <= b1; i += 8) {
+                float v[8];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) v[u] = parts[(size_t)(i + u) * n + e];
+                for (int u = 0; u < 8; ++u) v[u] = parts[(size_t)(i + u) * n + e];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) p += v[u];
-        }
-        for (; i + 8 <= nparts; i += 8) {
+                for (int u = 0; u < 8; ++u) pb += v[u];
+            }
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = parts[(size_t)(i + u) * n + e];
+            for (int u = 0; u < 8; ++u) v[u] = i + u < b1 ? parts[(size_t)(i + u) * n + e] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) p += v[u];
+            for (int u = 0; u < 8; ++u) pb += v[u];              // (a + 0.f is exact)
+            p += pb;
         }
-        for (; i < nparts; ++i) p += parts[(size_t)i * n + e];
         r = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(p) : (model == kModelOgiveLaplace ? sqrtf(p * inv_f_total) : p * inv_f_total);
         R[e] = r;
     }
@@ -61,12 +65,13 @@ __global__ __launch_bounds__(kBlock) void activation_kernel(const float* __restr
 }
 
 // The same with the bins sharded over the GPUs of a node and NO collective and NO host in the loop (the iteration stays a
-// captured graph of four kernels): every thread adds its rank's parts in order (the rank's sum of |y|^2 for its frame and
-// source), stores it -- one naturally aligned 8-byte word {value, epoch}, system scope -- into its slot of every OTHER
-// rank's gather buffer (peer stores over xGMI: T K 8 bytes per peer and iteration, 64 KB at the headline shape), polls its
-// own buffer until the other ranks' words carry this epoch, and adds the ranks' sums in rank order: the same bits of r on
-// every rank.  (Against the collective path, which gathers every 64-bin part and adds them one by one, the sum is
-// associated rank by rank: r differs in its last bits.)  The buffers alternate with the epoch's parity -- a rank can be one
+// captured graph of four kernels): every thread adds its rank's parts into the rank's BLOCK sums of the canonical order
+// (activation_kernel; a rank of 2 / 4 / 8 equal shards holds 4 / 2 / 1 of the 8 blocks), stores them -- naturally aligned
+// 8-byte words {value, epoch}, system scope -- into its slot of every OTHER rank's gather buffer (peer stores over xGMI:
+// T K 8 bytes per block, peer and iteration; 64-256 KB at the headline shape), polls its own buffer until the other
+// ranks' words carry this epoch, and adds all blocks in rank and block order: the same bits of r on every rank, and -- with
+// equal shards on whole blocks -- the same bits as the collective path and as ONE GPU.  (Shards that do not hold whole
+// blocks send one sum per rank: then r agrees with the other paths to rounding.)  The buffers alternate with the epoch's parity -- a rank can be one
 // iteration ahead of the slowest reader of its stores, never two: it cannot finish epoch e + 1 before every rank has
 // stored e + 1, which a rank does only after it has read epoch e.  The epoch is counted on the device, one word per
 // workgroup (read at the start, advanced at the end by the workgroup itself), so a replayed graph needs no new arguments.
@@ -75,6 +80,7 @@ __global__ __launch_bounds__(kBlock) void activation_kernel(const float* __restr
 struct ActXchgArgs {
     unsigned long long* gath[OIVA_XCHG_MAX_RANKS];      // every rank's [2][world][T * K] words, as mapped here
     int rank, world, loopback;                          // loopback 2: the phantom ranks never store (test hook: a rank that does not deliver)
+    int nblk_own, nblk_peer, bs;                        // block sums this rank forms (of bs parts; the last may be short) / words per other rank's slot (<= 8 each)
     unsigned* epochs;                                   // [gridDim.y][gridDim.x]
     unsigned* ctrl;
     long long timeout;
@@ -91,38 +97,57 @@ __global__ __launch_bounds__(kBlock) void activation_xchg_kernel(const float* __
     float r = 0.f;
     if (t < T) {
         const size_t e = (size_t)t * K + k;
-        float p = 0.f;
-        for (int i = 0; i < nparts; i += 8) {
-            float v[8];
+        // this rank's block sums (canonical order, see activation_kernel): nblk_own blocks of nparts / nblk_own parts
+        const int bs = a.bs;
+        float pb[kCanonBlocks];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = i + u < nparts ? parts[(size_t)(i + u) * n + e] : 0.f;
+        for (int b = 0; b < kCanonBlocks; ++b) {
+            pb[b] = 0.f;
+            if (b < a.nblk_own) {
+                const int b1 = min(nparts, (b + 1) * bs);
+                for (int i = b * bs; i < b1; i += 8) {
+                    float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) p += v[u];              // (a + 0.f is exact: the padding changes nothing)
+                    for (int u = 0; u < 8; ++u) v[u] = i + u < b1 ? parts[(size_t)(i + u) * n + e] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) pb[b] += v[u];
+                }
+            }
         }
-        const unsigned long long mine = (unsigned long long)__float_as_uint(p) | ((unsigned long long)epoch << 32);
-        const size_t base = (size_t)par * a.world * n + e;
+        // slot of rank q in a buffer: [nblk_peer][T * K] words
+        const size_t slot = (size_t)a.nblk_peer * n;
+        const size_t base = (size_t)par * a.world * slot + e;
         for (int q = 0; q < a.world && a.loopback != 2; ++q) {
             if (q == a.rank) continue;
-            unsigned long long* dst = a.loopback ? a.gath[a.rank] + base + (size_t)q * n : a.gath[q] + base + (size_t)a.rank * n;
-            __hip_atomic_store(dst, a.loopback ? ((unsigned long long)epoch << 32) : mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            unsigned long long* dst = a.loopback ? a.gath[a.rank] + base + (size_t)q * slot : a.gath[q] + base + (size_t)a.rank * slot;
+#pragma unroll
+            for (int b = 0; b < kCanonBlocks; ++b) {
+                if (b < a.nblk_peer) {
+                    const unsigned long long w = a.loopback ? 0ull : (unsigned long long)__float_as_uint(pb[b]);
+                    __hip_atomic_store(dst + (size_t)b * n, w | ((unsigned long long)epoch << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
         }
         const unsigned long long* own = a.gath[a.rank] + base;
         float tot = 0.f;
         const long long t0 = wall_clock64();
-        for (int q0 = 0; q0 < a.world; q0 += 8) {
-            float v[8];
+        for (int q = 0; q < a.world; ++q) {
+            if (q == a.rank) {              // (wave-uniform) own blocks, in order
+#pragma unroll
+                for (int b = 0; b < kCanonBlocks; ++b) tot += b < a.nblk_own ? pb[b] : 0.f;
+                continue;
+            }
+            float v[kCanonBlocks];
             for (unsigned spins = 1;; ++spins) {
                 bool ok = true;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int q = q0 + u < a.world ? q0 + u : a.world - 1;
-                    if (q == a.rank) {
-                        v[u] = p;
-                        continue;
+                for (int b = 0; b < kCanonBlocks; ++b) {
+                    v[b] = 0.f;
+                    if (b < a.nblk_peer) {
+                        const unsigned long long x = __hip_atomic_load(own + (size_t)q * slot + (size_t)b * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        ok = ok && (unsigned)(x >> 32) == epoch;
+                        v[b] = __uint_as_float((unsigned)x);
                     }
-                    const unsigned long long x = __hip_atomic_load(own + (size_t)q * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    ok = ok && (unsigned)(x >> 32) == epoch;
-                    v[u] = __uint_as_float((unsigned)x);
                 }
                 if (ok) break;
                 if ((spins & 15u) == 0u && (wall_clock64() - t0 > a.timeout || __hip_atomic_load(a.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
@@ -132,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void activation_xchg_kernel(const float* __
                 __builtin_amdgcn_s_sleep(2);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) tot += q0 + u < a.world ? v[u] : 0.f;          // rank order
+            for (int b = 0; b < kCanonBlocks; ++b) tot += b < a.nblk_peer ? v[b] : 0.f;          // rank order, block order
         }
         r = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(tot) : (model == kModelOgiveLaplace ? sqrtf(tot * inv_f_total) : tot * inv_f_total);
         R[e] = r;
@@ -223,8 +248,12 @@ hipError_t launch_activation(hipStream_t s, const float* parts, int nparts, floa
 }
 
 hipError_t launch_activation_xchg(hipStream_t s, const float* parts, int nparts, char* const* gath, int rank, int world, int loopback,
-                                  unsigned* epochs, unsigned* ctrl, long long timeout_ticks, float* R, int T, int K, int model, int F_total) {
+                                  int nblk_own, int nblk_peer, unsigned* epochs, unsigned* ctrl, long long timeout_ticks, float* R, int T, int K,
+                                  int model, int F_total) {
     ActXchgArgs a;
+    a.nblk_own = nblk_own;
+    a.nblk_peer = nblk_peer;
+    a.bs = (nparts + nblk_own - 1) / nblk_own;
     for (int r = 0; r < OIVA_XCHG_MAX_RANKS; ++r) a.gath[r] = r < world ? reinterpret_cast<unsigned long long*>(gath[r]) : nullptr;
     a.rank = rank;
     a.world = world;

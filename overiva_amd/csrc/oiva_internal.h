@@ -149,8 +149,10 @@ hipError_t pow_blocks_per_cu(int M, int kp, int tcp, int* n);
 
 // Source activation, overiva.py:152-155: parts [nparts][T][K] -> R (T,K) = 2 sqrt(p) | p / F_total.
 // activation with the exchange of the ranks' partial powers inside it (bins sharded over GPUs; kernels_misc.hip)
+constexpr int kCanonBlocks = 8;      // the sum over the 64-bin parts is associated in at most this many blocks (activation_kernel)
 hipError_t launch_activation_xchg(hipStream_t s, const float* parts, int nparts, char* const* gath, int rank, int world, int loopback,
-                                  unsigned* epochs, unsigned* ctrl, long long timeout_ticks, float* R, int T, int K, int model, int F_total);
+                                  int nblk_own, int nblk_peer, unsigned* epochs, unsigned* ctrl, long long timeout_ticks, float* R, int T, int K,
+                                  int model, int F_total);
 hipError_t launch_activation(hipStream_t s, const float* parts, int nparts, float* R, int T, int K, int model,
                              int F_total);
 // fixed-order float64 sum of partial buffers (float32, or float64 when f64): out[e] = scale * sum_i parts[i][e]

@@ -132,6 +132,7 @@ struct oiva_plan {
     bool fx_on = false, fx_loopback = false;
     char* fx_gath[OIVA_XCHG_MAX_RANKS] = {};
     int fx_rank = 0, fx_world = 1;
+    int fx_nblk_own = 1, fx_nblk_peer = 1;      // block sums this rank forms / words per other rank's slot
     char* fx_loop_buf = nullptr;                // loop-back: this plan's own gather buffer
     unsigned* fx_state = nullptr;               // [0] give-up flag, [16 ...] one epoch counter per workgroup of the activation kernel
     int fx_timeout_ms = 0, fx_stall = 0;
@@ -340,7 +341,7 @@ int stage_power(oiva_plan* p) {
 int stage_activation(oiva_plan* p, const float* parts, int nparts) {
     if (p->fx_on && parts == p->Ppart) {
         // bins sharded over GPUs, the ranks' sums exchanged by the activation kernel itself (no collective, no host in the loop)
-        HIP_TRY(launch_activation_xchg(p->stream, parts, nparts, p->fx_gath, p->fx_rank, p->fx_world, p->fx_loopback ? (p->fx_stall ? 2 : 1) : 0, p->fx_state + 16,
+        HIP_TRY(launch_activation_xchg(p->stream, parts, nparts, p->fx_gath, p->fx_rank, p->fx_world, p->fx_loopback ? (p->fx_stall ? 2 : 1) : 0, p->fx_nblk_own, p->fx_nblk_peer, p->fx_state + 16,
                                        p->fx_state, (long long)(p->fx_timeout_ms > 0 ? p->fx_timeout_ms : 2000) * 100000, p->R, p->T, p->K,
                                        p->model, p->F_total));
         p->raw_weights = 0;
@@ -1077,9 +1078,15 @@ int oiva_plan_fused_connect(oiva_plan* p, oiva_xchg* x) {
     int rank = 0, world = 1;
     size_t slot = 0;
     NEED(xchg_peers(x, peers, &rank, &world, &slot) == 0, OIVA_ERR_STATE, "exchange not connected");
-    NEED(slot == (size_t)p->T * p->K * 8, OIVA_ERR_ARG, "exchange slot size must be T * K * 8 bytes (one {value, epoch} word per frame and source)");
+    // slot = nblk * T * K * 8 bytes: nblk block sums per rank (every rank the same; 1 = the rank's sum)
+    const size_t word_bytes = (size_t)p->T * p->K * 8;
+    NEED(slot % word_bytes == 0 && slot / word_bytes >= 1 && slot / word_bytes <= (size_t)kCanonBlocks, OIVA_ERR_ARG,
+         "exchange slot size must be nblk * T * K * 8 bytes, nblk = 1 ... 8 block sums per rank");
+    const int nblk = (int)(slot / word_bytes);
+    NEED(p->pw.nb % nblk == 0, OIVA_ERR_ARG, "the plan's 64-bin parts do not divide into that many blocks");
     int rc = fused_setup(p);
     if (rc) return rc;
+    p->fx_nblk_own = p->fx_nblk_peer = nblk;
     for (int r = 0; r < OIVA_XCHG_MAX_RANKS; ++r) p->fx_gath[r] = peers[r];
     p->fx_rank = rank;
     p->fx_world = world;
@@ -1106,7 +1113,12 @@ int oiva_plan_fused_loopback(oiva_plan* p, int world) {
     if (world <= 1) return OIVA_OK;
     NEED(!p->fx_on, OIVA_ERR_STATE, "the plan is connected to other ranks (oiva_plan_fused_connect(p, NULL) disconnects)");
     NEED(p->F == p->F_total, OIVA_ERR_STATE, "loop-back plays the other ranks with zeros: the plan must own all bins");
-    const size_t bytes = (size_t)2 * world * p->T * p->K * 8;
+    // own blocks: those of the single-GPU sum (the result keeps its bits); per phantom rank the words a real rank of that
+    // world would send: 8 / world blocks
+    const int bsz = (p->pw.nb + kCanonBlocks - 1) / kCanonBlocks;
+    p->fx_nblk_own = (p->pw.nb + bsz - 1) / bsz;
+    p->fx_nblk_peer = std::max(1, kCanonBlocks / world);
+    const size_t bytes = (size_t)2 * world * p->fx_nblk_peer * p->T * p->K * 8;
     HIP_TRY(hipExtMallocWithFlags((void**)&p->fx_loop_buf, bytes, hipDeviceMallocFinegrained));
     HIP_TRY(hipMemset(p->fx_loop_buf, 0, bytes));
     int rc = fused_setup(p);

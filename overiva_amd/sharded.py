@@ -48,6 +48,22 @@ def shard_bounds(n_freq, world):
     return [n_freq * r // world for r in range(world + 1)]
 
 
+def fused_blocks(bounds):
+    """Block sums per rank for the exchange inside the activation kernel.  The library adds the 64-bin parts of the source
+    powers in a canonical order: blocks of ceil(parts / 8) consecutive parts, each added sequentially, then the block sums
+    sequentially (csrc/kernels_misc.hip).  Ranks with EQUAL shards made of whole blocks send their block sums and every rank
+    forms exactly that sum -- the same bits as one GPU (2 / 4 / 8 ranks at 2048 bins: 4 / 2 / 1 blocks each); any other
+    sharding sends one sum per rank (same bits on every rank, rounding-level difference to the single-GPU sum)."""
+    F = bounds[-1]
+    sizes = {bounds[r + 1] - bounds[r] for r in range(len(bounds) - 1)}
+    bs = -(-(-(-F // 64)) // 8)                  # parts per block of the whole problem
+    if len(sizes) == 1:
+        fl = sizes.pop()
+        if fl % (64 * bs) == 0 and 1 <= fl // (64 * bs) <= 8:
+            return fl // (64 * bs)
+    return 1
+
+
 class HipEngine:
     """the product engine: one ``Plan`` on this rank's GPU, launched on torch's current stream"""
 
@@ -191,7 +207,7 @@ class HipEngine:
     def iterate_resident(self, n):
         self.plan.iterate(n)
 
-    def setup_fused(self, dist, group, rank, world):
+    def setup_fused(self, dist, group, rank, world, nblk=1):
         """The exchange of the ranks' partial powers inside the activation kernel of the four-launch iteration (shards that do
         not fit on chip: 2 and 4 GPUs at the headline shape): no collective and no host in the loop, ``plan.iterate(n)``
         replays captured graphs of four kernels.  The ranks map each other's gather buffers (``PushExchange``, slot = T K 8
@@ -200,7 +216,7 @@ class HipEngine:
 
         x, ok, why, mineh = None, True, "", b"\0" * 64
         try:
-            x = PushExchange(self.device.index, rank, world, 0, self.T * self.K * 8, self.stream.cuda_stream)
+            x = PushExchange(self.device.index, rank, world, 0, nblk * self.T * self.K * 8, self.stream.cuda_stream)
             mineh = x.handle()
         except Exception as e:
             ok, why = False, f"{type(e).__name__}: {e}"
@@ -309,7 +325,7 @@ class BinShardedSolver:
         # "fused": the exchange inside the activation kernel of the four-launch iteration (any shard size)
         self.fused, self.fused_refused = False, None
         if want == "fused" and hasattr(self.engine, "setup_fused"):
-            self.fused_refused = self.engine.setup_fused(dist, group, self.rank, self.world)
+            self.fused_refused = self.engine.setup_fused(dist, group, self.rank, self.world, fused_blocks(self.bounds))
             self.fused = self.fused_refused is None
         if hasattr(self.engine, "plan"):
             from .exchange import make_exchange

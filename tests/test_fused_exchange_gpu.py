@@ -100,12 +100,14 @@ def _workers(tmp_path, world, T, F, M, K, model, precision, n_iter, port):
     return np.load(out)
 
 
-@pytest.mark.parametrize("world,F,model", [(2, 128, "laplace"), (3, 200, "gauss"), (4, 256, "laplace"), (8, 512, "laplace")])
+@pytest.mark.parametrize("world,F,model", [(2, 128, "laplace"), (3, 200, "gauss"), (4, 256, "laplace"), (8, 512, "laplace"),
+                                           (2, 1024, "laplace"), (2, 384, "gauss"), (4, 2048, "laplace")])
 def test_processes_sharing_one_gpu(oa, tmp_path, world, F, model):
     """real processes, one plan each on the box's one GPU, the exchange inside their activation kernels through IPC-mapped
     fine-grained buffers (across GPUs the stores travel over xGMI): callbacks, projection back and the gathers of the sharded
-    driver around graph replays.  Against the four-launch path in one process: the sum over the bins is associated rank by
-    rank instead of part by part, so W and Y agree to rounding, not bit for bit."""
+    driver around graph replays.  Against the four-launch path in ONE process: equal shards made of whole blocks of the
+    canonical sum (1024 bins on 2 ranks: 4 blocks of 2 parts each; 2048 on 4: 2 blocks of 4) send their block sums, and the
+    result is the single-GPU one BIT FOR BIT; unequal shards (200 bins on 3 ranks) send one sum per rank and agree to rounding."""
     T, M, K, n_iter = 300, 4, 2, 12
     got = _workers(tmp_path, world, T, F, M, K, model, "mixed", n_iter, 29700 + world)
     assert int(got["world"]) == world and str(got["exchange"]) == "fused", (str(got["exchange"]), str(got["refused"]))
@@ -118,6 +120,14 @@ def test_processes_sharing_one_gpu(oa, tmp_path, world, F, model):
     finally:
         oa.set_precision("auto")
         os.environ.pop("OIVA_RESIDENT", None)
+    from overiva_amd.sharded import fused_blocks, shard_bounds
+
     eW, eY = orc.rel_err(got["W"], W), orc.rel_err(got["Y"], Y)
-    print(f"\n[fused, {world} processes] W {eW:.1e} Y {eY:.1e}")
-    assert eW < 2e-5 and eY < 2e-5 and got["cb"].shape == np.stack(seen).shape
+    b = shard_bounds(F, world)
+    whole_blocks = len({b[r + 1] - b[r] for r in range(world)}) == 1 and (F // world) % (64 * -(-(-(-F // 64)) // 8)) == 0
+    print(f"\n[fused, {world} processes, {F} bins, {fused_blocks(b)} block(s) per rank] W {eW:.1e} Y {eY:.1e}")
+    assert got["cb"].shape == np.stack(seen).shape
+    if whole_blocks:
+        assert np.array_equal(got["W"], W) and np.array_equal(got["Y"], Y) and np.array_equal(got["cb"], np.stack(seen))
+    else:
+        assert eW < 2e-5 and eY < 2e-5
