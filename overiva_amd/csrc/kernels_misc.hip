@@ -128,36 +128,50 @@ __global__ __launch_bounds__(kBlock) void activation_xchg_kernel(const float* __
                 }
             }
         }
-        const unsigned long long* own = a.gath[a.rank] + base;
-        float tot = 0.f;
+        // Poll: the words of ALL other ranks requested together (<= 8: 7 x 1, 3 x 2 or 1 x 4 blocks at 8 / 4 / 2 equal shards),
+        // as buffer loads with the system-scope cache bits -- an atomic load would be followed by s_waitcnt vmcnt(0), i.e. one
+        // round trip to the (uncached, fine-grained) buffer per word instead of one per pass.
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.gath[a.rank], 0, (int)((size_t)2 * a.world * slot * 8), 0x00020000);
+        const int npeer = a.world - 1;
+        float vq[kCanonBlocks];
         const long long t0 = wall_clock64();
+        for (unsigned spins = 1;; ++spins) {
+            unsigned long long x[kCanonBlocks];
+#pragma unroll
+            for (int w = 0; w < kCanonBlocks; ++w) {
+                // word w of the pass: block w % nblk_peer of the (w / nblk_peer)-th OTHER rank
+                const int pi = w / a.nblk_peer, b = w - pi * a.nblk_peer;
+                const int q = pi < a.rank ? pi : pi + 1;
+                const bool live = pi < npeer;
+                const size_t off = live ? (base + (size_t)q * slot + (size_t)b * n) * 8 : base * 8;
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, 0, /*sc0 sc1: system scope*/ 17);
+                x[w] = (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);
+                if (!live) x[w] = (unsigned long long)epoch << 32;
+            }
+            bool ok = true;
+#pragma unroll
+            for (int w = 0; w < kCanonBlocks; ++w) {
+                ok = ok && (unsigned)(x[w] >> 32) == epoch;
+                vq[w] = __uint_as_float((unsigned)x[w]);
+            }
+            if (ok) break;
+            if ((spins & 15u) == 0u && (wall_clock64() - t0 > a.timeout || __hip_atomic_load(a.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                atomicCAS(a.ctrl, 0u, 1u + (unsigned)blockIdx.x);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        // all blocks in rank order, block order (own blocks from registers)
+        float tot = 0.f;
         for (int q = 0; q < a.world; ++q) {
-            if (q == a.rank) {              // (wave-uniform) own blocks, in order
+            if (q == a.rank) {
 #pragma unroll
                 for (int b = 0; b < kCanonBlocks; ++b) tot += b < a.nblk_own ? pb[b] : 0.f;
-                continue;
-            }
-            float v[kCanonBlocks];
-            for (unsigned spins = 1;; ++spins) {
-                bool ok = true;
+            } else {
+                const int pi = q < a.rank ? q : q - 1;
 #pragma unroll
-                for (int b = 0; b < kCanonBlocks; ++b) {
-                    v[b] = 0.f;
-                    if (b < a.nblk_peer) {
-                        const unsigned long long x = __hip_atomic_load(own + (size_t)q * slot + (size_t)b * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        ok = ok && (unsigned)(x >> 32) == epoch;
-                        v[b] = __uint_as_float((unsigned)x);
-                    }
-                }
-                if (ok) break;
-                if ((spins & 15u) == 0u && (wall_clock64() - t0 > a.timeout || __hip_atomic_load(a.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                    atomicCAS(a.ctrl, 0u, 1u + (unsigned)blockIdx.x);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
+                for (int w = 0; w < kCanonBlocks; ++w) tot += (w >= pi * a.nblk_peer && w < (pi + 1) * a.nblk_peer) ? vq[w] : 0.f;
             }
-#pragma unroll
-            for (int b = 0; b < kCanonBlocks; ++b) tot += b < a.nblk_peer ? v[b] : 0.f;          // rank order, block order
         }
         r = model == OIVA_MODEL_LAPLACE ? 2.f * sqrtf(tot) : (model == kModelOgiveLaplace ? sqrtf(tot * inv_f_total) : tot * inv_f_total);
         R[e] = r;

@@ -1084,6 +1084,7 @@ int oiva_plan_fused_connect(oiva_plan* p, oiva_xchg* x) {
          "exchange slot size must be nblk * T * K * 8 bytes, nblk = 1 ... 8 block sums per rank");
     const int nblk = (int)(slot / word_bytes);
     NEED(p->pw.nb % nblk == 0, OIVA_ERR_ARG, "the plan's 64-bin parts do not divide into that many blocks");
+    NEED((world - 1) * nblk <= kCanonBlocks, OIVA_ERR_ARG, "the activation kernel polls at most 8 words of the other ranks per frame and source (9 ranks of one sum each)");
     int rc = fused_setup(p);
     if (rc) return rc;
     p->fx_nblk_own = p->fx_nblk_peer = nblk;
@@ -1118,6 +1119,7 @@ int oiva_plan_fused_loopback(oiva_plan* p, int world) {
     const int bsz = (p->pw.nb + kCanonBlocks - 1) / kCanonBlocks;
     p->fx_nblk_own = (p->pw.nb + bsz - 1) / bsz;
     p->fx_nblk_peer = std::max(1, kCanonBlocks / world);
+    NEED((world - 1) * p->fx_nblk_peer <= kCanonBlocks, OIVA_ERR_ARG, "at most 9 ranks");
     const size_t bytes = (size_t)2 * world * p->fx_nblk_peer * p->T * p->K * 8;
     HIP_TRY(hipExtMallocWithFlags((void**)&p->fx_loop_buf, bytes, hipDeviceMallocFinegrained));
     HIP_TRY(hipMemset(p->fx_loop_buf, 0, bytes));
