@@ -22,6 +22,7 @@
 // partials.  Frames past the end of a split take their weights from the zeroed row T of the table.
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "oiva_device.h"
 #include "cov_arith.h"
@@ -446,6 +447,13 @@ hipError_t launch_cov_half16(hipStream_t s, const float2* X, const float* R, flo
     hipError_t e = launch_cov_weights(s, R, Wt, wscale, model, raw, T, K, kH16WeightStride);
     if (e == hipSuccess) e = hipMemsetAsync(Wt + (size_t)T * kH16WeightStride, 0, kH16WeightStride * sizeof(float), s);
     if (e != hipSuccess) return e;
+    // nine and more sources: the weighted sums of all sources as one small GEMM per bin on the fp32 matrix cores, the
+    // Hermitian products on the vector ALU beside it (kernels_cov_hmfma.hip); $OIVA_COV_HMFMA=0 keeps the vector-ALU kernel
+    static const bool hmfma = [] {
+        const char* v = std::getenv("OIVA_COV_HMFMA");
+        return !(v && v[0] == '0');
+    }();
+    if (hmfma && cov_hmfma_supported(M, K)) return launch_cov_hmfma(s, X, Wt, Vpart, T, F, M, Mv, K, g);
     if (K <= 8)
         return launch_dominant(cov_half16_kernel<4, false>, grid, block, 0, s, X, (const float*)Wt, Vpart, T, F, M, Mv, K, g.tc);
     if (K <= 12)
