@@ -213,6 +213,9 @@ int oiva_plan_set_cov_splits(oiva_plan *p, int nsplit);
 int oiva_plan_set_cov_quad(oiva_plan *p, int enable, int *active);
 /* same for the demix+power pass (0 = library default) */
 int oiva_plan_set_pow_splits(oiva_plan *p, int nsplit);
+/* 10..16 channels with 9..16 sources: the covariance pass with the sources on the fp32 matrix cores (default, csrc/kernels_cov_hmfma.hip)
+ * or on the vector ALU alone (enable = 0; same bits: A/B tests). */
+int oiva_plan_set_cov_hmfma(oiva_plan *p, int enable);
 /* Replay the iteration from a captured hipGraph instead of eager launches (default off). */
 int oiva_plan_use_graph(oiva_plan *p, int enable);
 /* Arithmetic: an OR of OIVA_PREC_* (default OIVA_PREC_FAST).  Call it before oiva_plan_covariance so that the

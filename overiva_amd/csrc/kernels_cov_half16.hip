@@ -448,12 +448,8 @@ hipError_t launch_cov_half16(hipStream_t s, const float2* X, const float* R, flo
     if (e == hipSuccess) e = hipMemsetAsync(Wt + (size_t)T * kH16WeightStride, 0, kH16WeightStride * sizeof(float), s);
     if (e != hipSuccess) return e;
     // nine and more sources: the weighted sums of all sources as one small GEMM per bin on the fp32 matrix cores, the
-    // Hermitian products on the vector ALU beside it (kernels_cov_hmfma.hip); $OIVA_COV_HMFMA=0 keeps the vector-ALU kernel
-    static const bool hmfma = [] {
-        const char* v = std::getenv("OIVA_COV_HMFMA");
-        return !(v && v[0] == '0');
-    }();
-    if (hmfma && cov_hmfma_supported(M, K)) return launch_cov_hmfma(s, X, Wt, Vpart, T, F, M, Mv, K, g);
+    // Hermitian products on the vector ALU beside it (kernels_cov_hmfma.hip; CovGeom::hmfma, on by default)
+    if (g.hmfma && cov_hmfma_supported(M, K)) return launch_cov_hmfma(s, X, Wt, Vpart, T, F, M, Mv, K, g);
     if (K <= 8)
         return launch_dominant(cov_half16_kernel<4, false>, grid, block, 0, s, X, (const float*)Wt, Vpart, T, F, M, Mv, K, g.tc);
     if (K <= 12)

@@ -37,11 +37,17 @@ constexpr int kHmWeightStride = 16;                     // row stride of the wei
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
-// the lane's operands of one bin of one stage: its own row channel, the 16 column channels (8 x 16 bytes, the same
-// addresses in the 16 lanes of a frame: broadcast reads), and -- with the first bin -- its weight; the counted wait for the
-// stage's two DMAs in front.  asm: hipcc drains the whole DMA queue in front of any LDS read it can see.
+// The lane's operands of one bin of one stage: its own row channel, the 16 column channels (8 x 16 bytes, the same addresses
+// in the 16 lanes of a frame: broadcast reads) and -- with the first bin -- its weight, with the counted wait for the stage's
+// two DMAs in front.  asm: hipcc drains the whole DMA queue in front of any LDS read it can see.  The reads are ISSUED by
+// one statement and WAITED for by another (which names every destination), so that the second bin's reads fly while the
+// first bin's matrix instructions issue.
+struct HmOps {
+    float2 row;
+    float4 c[8];
+};
 template <bool FIRST>
-__device__ __forceinline__ void hm_read(unsigned a_row, unsigned a_cols, unsigned a_w, float2& row, float4 (&c)[8], float& w) {
+__device__ __forceinline__ void hm_read_issue(unsigned a_row, unsigned a_cols, unsigned a_w, HmOps& o, float& w) {
     if constexpr (FIRST) {
         asm volatile(
             "s_waitcnt vmcnt(%11)\n\t"
@@ -54,9 +60,9 @@ __device__ __forceinline__ void hm_read(unsigned a_row, unsigned a_cols, unsigne
             "ds_read_b128 %5, %13 offset:64\n\t"
             "ds_read_b128 %6, %13 offset:80\n\t"
             "ds_read_b128 %7, %13 offset:96\n\t"
-            "ds_read_b128 %8, %13 offset:112\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(row), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]), "=&v"(w)
+            "ds_read_b128 %8, %13 offset:112"
+            : "=&v"(o.row), "=&v"(o.c[0]), "=&v"(o.c[1]), "=&v"(o.c[2]), "=&v"(o.c[3]), "=&v"(o.c[4]), "=&v"(o.c[5]), "=&v"(o.c[6]), "=&v"(o.c[7]),
+              "=&v"(w)
             : "v"(a_row), "n"(2 * (kHmStages - 1)), "v"(a_w), "v"(a_cols)
             : "memory");
     } else {
@@ -69,12 +75,17 @@ __device__ __forceinline__ void hm_read(unsigned a_row, unsigned a_cols, unsigne
             "ds_read_b128 %5, %10 offset:64\n\t"
             "ds_read_b128 %6, %10 offset:80\n\t"
             "ds_read_b128 %7, %10 offset:96\n\t"
-            "ds_read_b128 %8, %10 offset:112\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(row), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+            "ds_read_b128 %8, %10 offset:112"
+            : "=&v"(o.row), "=&v"(o.c[0]), "=&v"(o.c[1]), "=&v"(o.c[2]), "=&v"(o.c[3]), "=&v"(o.c[4]), "=&v"(o.c[5]), "=&v"(o.c[6]), "=&v"(o.c[7])
             : "v"(a_row), "v"(a_cols)
             : "memory");
     }
+}
+// (the wait names no register -- tied operands of struct members are not supported -- so a scheduling barrier behind it keeps
+//  every consumer of the destinations below it)
+__device__ __forceinline__ void hm_read_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __restrict__ X, const float* __restrict__ Wt,
@@ -123,32 +134,34 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     const unsigned a_w0 = (unsigned)(uintptr_t)wring + (unsigned)kHmX + 4u * (unsigned)lane;
     const unsigned binoff = (unsigned)(M * 8);
 
-    // one stage: both bins; per column channel j the products of the lane's row with it -- Re(x_n conj x_j) for n <= j,
-    // Im(x_j conj x_n) below the diagonal -- and one MFMA with the stage's weights
+    // the 16 column channels of one bin: per column j the product of the lane's row n with it -- Re(x_n conj x_j) for n <= j,
+    // Im(x_j conj x_n) below the diagonal, each rounded exactly as kernels_cov_half16.hip rounds it (a product, then an FMA
+    // onto it), so that the two kernels give the same bits -- and one MFMA with the stage's weights
+    auto columns = [&](const HmOps& o, float w, f32x4 (&a)[16]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < M) {                                      // (wave-uniform)
+                const float xr = (j & 1) ? o.c[j >> 1].z : o.c[j >> 1].x, xi = (j & 1) ? o.c[j >> 1].w : o.c[j >> 1].y;
+                const bool up = n <= j;
+                // up:    re = fma(row.y, xi, row.x * xr)                      (entry (n, j), a = x_n, b = x_j)
+                // below: im = fma(xi, row.x, -(xr * row.y))                   (entry (j, n), a = x_j, b = x_n)
+                const float u = up ? o.row.y : o.row.x, s1 = up ? o.row.x : o.row.y, t1 = up ? xr : -xr;
+                const float hv = fmaf(u, xi, s1 * t1);
+                a[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, hv, a[j], 0, 0, 0);
+            }
+        }
+    };
+    // one stage: both bins; the second bin's operands are read while the first bin's matrix instructions issue
     auto stage = [&](int s) {
         const unsigned so = (unsigned)(s * kHmStage);
-        float w = 0.f;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float2 row;
-            float4 c[8];
-            if (h == 0)
-                hm_read<true>(a_row0 + so, lbase + so, a_w0 + so, row, c, w);
-            else
-                hm_read<false>(a_row0 + so + binoff, lbase + so + binoff, 0u, row, c, w);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (j < M) {                                      // (wave-uniform)
-                    const float xr = (j & 1) ? c[j >> 1].z : c[j >> 1].x, xi = (j & 1) ? c[j >> 1].w : c[j >> 1].y;
-                    const bool up = n <= j;
-                    const float a = up ? xr : xi, b = up ? xi : -xr;
-                    const float hv = fmaf(row.y, b, row.x * a);
-                    acc[h][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, hv, acc[h][j], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        float w, wdummy = 0.f;
+        HmOps o0, o1;
+        hm_read_issue<true>(a_row0 + so, lbase + so, a_w0 + so, o0, w);
+        hm_read_wait();
+        hm_read_issue<false>(a_row0 + so + binoff, lbase + so + binoff, 0u, o1, wdummy);
+        columns(o0, w, acc[0]);
+        hm_read_wait();
+        columns(o1, w, acc[1]);
     };
 
     issue(0, 0);

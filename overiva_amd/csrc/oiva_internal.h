@@ -67,6 +67,7 @@ struct CovGeom {
     int tc;       // frames per split (multiple of 16)
     int kc;       // sources per pass (template KC)
     int nbg;      // bin groups of 16 (grid.x)
+    int hmfma = 0;  // with half16, 9..16 sources: the sources on the fp32 matrix cores (kernels_cov_hmfma.hip)
     int half16 = 0; // 10/12/14/16 channels (9..15 odd: padded copy): kernels_cov_half16.hip (2 bins per workgroup; float32: 5..16 sources, all per pass; float64: 3..16 sources, 4 or 8 per pass)
     int pair32 = 0; // 8 channels, >= 3 sources, float32: kernels_cov_pair32.hip (32 bins per workgroup, four sources per pass)
     int pad = 0;  // odd channel count on the vector-ALU kernels: they read the copy of X padded to M + 1 channels

@@ -76,6 +76,7 @@ struct oiva_plan {
 
     CovGeom cov{};
     bool cov_quad_on = true;      // oiva_plan_set_cov_quad
+    bool cov_hmfma_on = true;     // oiva_plan_set_cov_hmfma ($OIVA_COV_HMFMA=0: off)
     CovGeom stg{};              // geometry of the projection-back statistics pass (16-bin groups, independent of cov)
     PowGeom pw{};
     int n_cu = 256;
@@ -205,6 +206,7 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     if (p->M > 8 && p->cov_quad_on &&
         (p->cov_f64() ? cov_half16_f64_supported(Mc, p->K) : p->K > 4 && cov_half16_supported(Mc, p->K))) {
         g.half16 = 1;
+        g.hmfma = (!p->cov_f64() && p->cov_hmfma_on && cov_hmfma_supported(Mc, p->K)) ? 1 : 0;
         g.nbg = ceil_div(p->F, 2);
         g.kc = p->cov_f64() ? cov_half16_f64_sources_per_pass(p->K) : cov_half16_sources_per_pass(p->K);
         if (nsplit <= 0) {
@@ -666,6 +668,10 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
             oiva_plan_destroy(p);
             return fail(OIVA_ERR_HIP, std::string("allocation of the padded copy of X failed: ") + hipGetErrorString(ep));
         }
+    }
+    {
+        const char* v = std::getenv("OIVA_COV_HMFMA");
+        p->cov_hmfma_on = !(v && v[0] == '0');
     }
     choose_cov_geom(p, 0);
     choose_pow_geom(p, 0);
@@ -1247,6 +1253,17 @@ int oiva_plan_set_cov_quad(oiva_plan* p, int enable, int* active) {
     p->cov_quad_on = enable != 0;
     choose_cov_geom(p, 0);
     if (active) *active = p->cov.quad || p->cov.half16;
+    return ensure_vpart(p);
+}
+
+int oiva_plan_set_cov_hmfma(oiva_plan* p, int enable) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    int rc = drop_graph(p);
+    if (rc) return rc;
+    p->cov_hmfma_on = enable != 0;
+    choose_cov_geom(p, 0);
     return ensure_vpart(p);
 }
 

@@ -216,6 +216,10 @@ class Plan:
         _lib.check(self.lib.oiva_plan_set_cov_quad(self.h, 1 if enable else 0, C.byref(a)))
         return bool(a.value)
 
+    def set_cov_hmfma(self, enable=True):
+        """9..16 sources on 10..16 channels: the sources on the fp32 matrix cores (default) or the vector-ALU kernel alone"""
+        _lib.check(self.lib.oiva_plan_set_cov_hmfma(self.h, 1 if enable else 0))
+
     def set_pow_splits(self, n):
         _lib.check(self.lib.oiva_plan_set_pow_splits(self.h, int(n)))
 

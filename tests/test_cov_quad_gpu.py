@@ -211,3 +211,26 @@ def test_16_channels_2_sources_full_size_properties(oa, mode):
     for f in (0, 1023, 2047):
         ref = orc.weighted_cov_all(X[:, f:f + 1, :], rinv.astype(np.float64))[:, 0]
         assert orc.rel_err(V[:, f], ref) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(400, 6, 16, 16), (333, 5, 16, 9), (250, 3, 12, 12), (200, 4, 14, 11), (180, 3, 15, 15), (170, 2, 11, 10)])
+def test_sources_on_the_matrix_cores_give_the_bits_of_the_vector_alu_kernel(oa, shape):
+    """9..16 sources: the weighted sums of all sources as one small GEMM per bin on the fp32 matrix cores
+    (csrc/kernels_cov_hmfma.hip) -- the Hermitian products are rounded as the vector-ALU kernel rounds them and the fp32
+    matrix instruction is an exact fmaf chain in frame order, so both kernels must produce the SAME float64 partial sums;
+    and both sit within the single-pass bound of the oracle"""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F, M, seed=31)
+    rinv = np.random.default_rng(5).gamma(2.0, 1.0, (T, K)).astype(np.float32)
+    V = {}
+    for on in (True, False):
+        with oa.Plan(T, F, M, K, "laplace") as p:
+            p.set_precision("mixed")
+            p.set_cov_hmfma(on)
+            p.set_x(X)
+            p.covariance()
+            p.t_set_rinv(rinv)
+            p.t_run_weighted_cov()
+            V[on] = p.t_get_v(np.complex128)
+    assert np.array_equal(V[True], V[False])
+    assert orc.rel_err(V[True], orc.weighted_cov_all(X, rinv.astype(np.float64))) < 3e-6
