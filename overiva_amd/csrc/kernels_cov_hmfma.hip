@@ -3,17 +3,19 @@
 //
 //   V_k[f] = sum_t rinv[t,k] * x_{t,f} x_{t,f}^H          reference overiva.py:179, all K sources in one pass over X
 //
-// Per (bin, frame) the Hermitian half of x x^H is 256 real numbers (16 x 16: the upper triangle holds the real parts, the
-// strict lower triangle the imaginary parts), and the weighted sums of ALL sources are one small GEMM per bin:
-//       V[k][e] = sum_t w[k][t] * H[t][e]        k: 16 sources, e: 256 packed entries, t: frames
-// i.e. per 4 frames 16 instructions v_mfma_f32_16x16x4_f32 -- A = the weights (16 sources x 4 frames), B = one column j of
-// H for those 4 frames (4 frames x 16 rows i), D = 16 sources x 16 rows -- for all 16 sources together, where the planar
+// Per (bin, frame) the Hermitian half of x x^H is M^2 real numbers, and the weighted sums of ALL sources are one small GEMM
+// per bin:   V[k][e] = sum_t w[k][t] * H[t][e]        k: 16 sources, e: the packed entries, t: frames
+// -- per 4 frames one v_mfma_f32_16x16x4_f32 per group of 16 entries: A = the weights (16 sources x 4 frames), B = 16
+// entries of H for those 4 frames, D = 16 sources x 16 entries -- for all 16 sources together, where the planar
 // matrix-core kernel (kernels_cov_mfma.hip: rank-1 updates of full real 16 x 16 tiles, 3 instructions per 4 frames and
-// SOURCE) issues 48 and the vector-ALU kernel (kernels_cov_half16.hip) spends one packed FMA per entry and source.  The
-// products H are formed on the vector ALU (4 instructions per lane and column: two selects by "row <= column", a multiply,
-// an FMA) while the matrix pipe runs: 128 vector instructions against 32 matrix instructions (1 024 matrix-pipe cycles)
-// per wave and stage.  The fp32 matrix instruction is an exact fmaf chain, so the arithmetic class is that of the
-// vector-ALU kernel: float32 products, float32 chains of T / (4 nsplit) frames, float64 sums across waves and splits.
+// SOURCE) issues 48 and the vector-ALU kernel (kernels_cov_half16.hip) spends one packed FMA per entry and source.
+// The 16 entries of a group are the CYCLIC diagonal c of the matrix: lane n forms the product of channel n with channel
+// (n + c) mod M -- c = 0: |x_n|^2; c = 1 .. M/2: real and imaginary part (two groups; at c = M/2 the lanes n >= M/2 repeat
+// the others and are dropped) -- so that every lane runs the same two instructions per group (a multiply and an FMA, no
+// select), which is what fits beside a matrix instruction: the pipe takes one every 32 cycles and hides about five issue
+// slots (MI355X_MICROARCH.md).  M + 1 matrix instructions per bin and 4 frames (17 at 16 channels).  The fp32 matrix
+// instruction is an exact fmaf chain in frame order, so the arithmetic class is that of the vector-ALU kernel: float32
+// products, float32 chains of T / (4 nsplit) frames, float64 sums across waves and splits.
 //
 // Geometry and memory exactly as kernels_cov_half16.hip: a workgroup = 2 bins x 4 frame phases (waves), one
 // global_load_lds per wave and stage moves 4 frames x 256 bytes into a 4-stage ring; the 64 weights of a stage (4 frames x
@@ -37,49 +39,33 @@ constexpr int kHmWeightStride = 16;                     // row stride of the wei
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
-// The lane's operands of one bin of one stage: its own row channel, the 16 column channels (8 x 16 bytes, the same addresses
-// in the 16 lanes of a frame: broadcast reads) and -- with the first bin -- its weight, with the counted wait for the stage's
-// two DMAs in front.  asm: hipcc drains the whole DMA queue in front of any LDS read it can see.  The reads are ISSUED by
-// one statement and WAITED for by another (which names every destination), so that the second bin's reads fly while the
-// first bin's matrix instructions issue.
+// The lane's operands of one bin of one stage: its own channel n and the channels (n + c) mod M, c = 1 .. 8 (nine 8-byte LDS
+// reads at per-lane addresses) and -- with the first bin -- its weight, with the counted wait for the stage's two DMAs in
+// front.  asm: hipcc drains the whole DMA queue in front of any LDS read it can see.  The reads are ISSUED by one statement
+// and WAITED for by another, so that the second bin's reads fly while the first bin's matrix instructions issue.
 struct HmOps {
     float2 row;
-    float4 c[8];
+    float2 x[8];
 };
 template <bool FIRST>
-__device__ __forceinline__ void hm_read_issue(unsigned a_row, unsigned a_cols, unsigned a_w, HmOps& o, float& w) {
+__device__ __forceinline__ void hm_read_issue(unsigned base, const unsigned (&ao)[9], unsigned a_w, HmOps& o, float& w) {
     if constexpr (FIRST) {
-        asm volatile(
-            "s_waitcnt vmcnt(%11)\n\t"
-            "ds_read_b32 %9, %12\n\t"
-            "ds_read_b64 %0, %10\n\t"
-            "ds_read_b128 %1, %13\n\t"
-            "ds_read_b128 %2, %13 offset:16\n\t"
-            "ds_read_b128 %3, %13 offset:32\n\t"
-            "ds_read_b128 %4, %13 offset:48\n\t"
-            "ds_read_b128 %5, %13 offset:64\n\t"
-            "ds_read_b128 %6, %13 offset:80\n\t"
-            "ds_read_b128 %7, %13 offset:96\n\t"
-            "ds_read_b128 %8, %13 offset:112"
-            : "=&v"(o.row), "=&v"(o.c[0]), "=&v"(o.c[1]), "=&v"(o.c[2]), "=&v"(o.c[3]), "=&v"(o.c[4]), "=&v"(o.c[5]), "=&v"(o.c[6]), "=&v"(o.c[7]),
-              "=&v"(w)
-            : "v"(a_row), "n"(2 * (kHmStages - 1)), "v"(a_w), "v"(a_cols)
-            : "memory");
-    } else {
-        asm volatile(
-            "ds_read_b64 %0, %9\n\t"
-            "ds_read_b128 %1, %10\n\t"
-            "ds_read_b128 %2, %10 offset:16\n\t"
-            "ds_read_b128 %3, %10 offset:32\n\t"
-            "ds_read_b128 %4, %10 offset:48\n\t"
-            "ds_read_b128 %5, %10 offset:64\n\t"
-            "ds_read_b128 %6, %10 offset:80\n\t"
-            "ds_read_b128 %7, %10 offset:96\n\t"
-            "ds_read_b128 %8, %10 offset:112"
-            : "=&v"(o.row), "=&v"(o.c[0]), "=&v"(o.c[1]), "=&v"(o.c[2]), "=&v"(o.c[3]), "=&v"(o.c[4]), "=&v"(o.c[5]), "=&v"(o.c[6]), "=&v"(o.c[7])
-            : "v"(a_row), "v"(a_cols)
-            : "memory");
+        asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w), "n"(2 * (kHmStages - 1)) : "memory");
     }
+    asm volatile(
+        "ds_read_b64 %0, %9\n\t"
+        "ds_read_b64 %1, %10\n\t"
+        "ds_read_b64 %2, %11\n\t"
+        "ds_read_b64 %3, %12\n\t"
+        "ds_read_b64 %4, %13\n\t"
+        "ds_read_b64 %5, %14\n\t"
+        "ds_read_b64 %6, %15\n\t"
+        "ds_read_b64 %7, %16\n\t"
+        "ds_read_b64 %8, %17"
+        : "=&v"(o.row), "=&v"(o.x[0]), "=&v"(o.x[1]), "=&v"(o.x[2]), "=&v"(o.x[3]), "=&v"(o.x[4]), "=&v"(o.x[5]), "=&v"(o.x[6]), "=&v"(o.x[7])
+        : "v"(base + ao[0]), "v"(base + ao[1]), "v"(base + ao[2]), "v"(base + ao[3]), "v"(base + ao[4]), "v"(base + ao[5]), "v"(base + ao[6]),
+          "v"(base + ao[7]), "v"(base + ao[8])
+        : "memory");
 }
 // (the wait names no register -- tied operands of struct members are not supported -- so a scheduling barrier behind it keeps
 //  every consumer of the destinations below it)
@@ -104,11 +90,14 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     const int t_end = min(T, t_begin + tc);
     const int nstages = (t_end - t_begin + 4 * kHmFrames - 1) / (4 * kHmFrames);
 
-    f32x4 acc[2][16];                                   // [bin of the pair][column channel j]: sources 4 q + r, row channel n
+    // [bin of the pair][group]: group 0 = |x_n|^2, 2 c - 1 / 2 c = real / imaginary part of x_n conj(x_(n + c) mod M), c = 1 .. 8;
+    // lane (q, n) holds sources 4 q + r of its entry
+    f32x4 acc[2][17];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 17; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int MH = M / 2;
 
     // ---- DMA side (as kernels_cov_half16.hip): lane l moves 16-byte piece l & 15 of frame l >> 4 of the stage; the wave's
     //      frames are t_begin + wave + 4 n, a stage holds n = 4 i .. 4 i + 3.  The weights of the same 4 frames: lane l moves
@@ -127,27 +116,26 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
         __builtin_amdgcn_global_load_lds((gvoid_t*)(Wt + (size_t)tw * kHmWeightStride + n), (lvoid_t*)(wring + s * kHmStage + kHmX), 4, 0, 0);
     };
 
-    // ---- operand addresses of this lane inside stage 0 (bin h at + h * M * 8; reads past M channels stay inside the slot
-    //      and only reach entries that are dropped)
+    // ---- operand addresses of this lane inside a frame slot of bin 0 (bin h at + h * M * 8): its own channel, then the
+    //      channels (n + c) mod M; lanes n >= M (fewer than 16 channels) read channel 0 and produce entries that are dropped
     const unsigned lbase = (unsigned)(uintptr_t)wring + (unsigned)(q * kHmSlot);
-    const unsigned a_row0 = lbase + 8u * (unsigned)(n < M ? n : 0);
+    const int nn = n < M ? n : 0;
+    unsigned ao[9];
+    ao[0] = 8u * (unsigned)nn;
+#pragma unroll
+    for (int c = 1; c <= 8; ++c) ao[c] = 8u * (unsigned)((nn + c) % M);
     const unsigned a_w0 = (unsigned)(uintptr_t)wring + (unsigned)kHmX + 4u * (unsigned)lane;
     const unsigned binoff = (unsigned)(M * 8);
 
-    // the 16 column channels of one bin: per column j the product of the lane's row n with it -- Re(x_n conj x_j) for n <= j,
-    // Im(x_j conj x_n) below the diagonal, each rounded exactly as kernels_cov_half16.hip rounds it (a product, then an FMA
-    // onto it), so that the two kernels give the same bits -- and one MFMA with the stage's weights
-    auto columns = [&](const HmOps& o, float w, f32x4 (&a)[16]) {
+    // the M + 1 groups of one bin: a product (multiply, FMA onto it) and one MFMA with the stage's weights each
+    auto groups = [&](const HmOps& o, float w, f32x4 (&a)[17]) {
+        a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, o.row.y, o.row.x * o.row.x), a[0], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j < M) {                                      // (wave-uniform)
-                const float xr = (j & 1) ? o.c[j >> 1].z : o.c[j >> 1].x, xi = (j & 1) ? o.c[j >> 1].w : o.c[j >> 1].y;
-                const bool up = n <= j;
-                // up:    re = fma(row.y, xi, row.x * xr)                      (entry (n, j), a = x_n, b = x_j)
-                // below: im = fma(xi, row.x, -(xr * row.y))                   (entry (j, n), a = x_j, b = x_n)
-                const float u = up ? o.row.y : o.row.x, s1 = up ? o.row.x : o.row.y, t1 = up ? xr : -xr;
-                const float hv = fmaf(u, xi, s1 * t1);
-                a[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, hv, a[j], 0, 0, 0);
+        for (int c = 1; c <= 8; ++c) {
+            if (c <= MH) {                                    // (wave-uniform)
+                const float2 x = o.x[c - 1];
+                a[2 * c - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, x.y, o.row.x * x.x), a[2 * c - 1], 0, 0, 0);     // Re x_n conj x_m
+                a[2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, x.x, -(o.row.x * x.y)), a[2 * c], 0, 0, 0);         // Im x_n conj x_m
             }
         }
     };
@@ -156,12 +144,12 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
         const unsigned so = (unsigned)(s * kHmStage);
         float w, wdummy = 0.f;
         HmOps o0, o1;
-        hm_read_issue<true>(a_row0 + so, lbase + so, a_w0 + so, o0, w);
+        hm_read_issue<true>(lbase + so, ao, a_w0 + so, o0, w);
         hm_read_wait();
-        hm_read_issue<false>(a_row0 + so + binoff, lbase + so + binoff, 0u, o1, wdummy);
-        columns(o0, w, acc[0]);
+        hm_read_issue<false>(lbase + so + binoff, ao, 0u, o1, wdummy);
+        groups(o0, w, acc[0]);
         hm_read_wait();
-        columns(o1, w, acc[1]);
+        groups(o1, w, acc[1]);
     };
 
     issue(0, 0);
@@ -173,33 +161,46 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the DMA queue before the ring becomes reduction scratch
 
-    // ---- the four waves (frame phases) added in float64, fixed order; accumulator m = (h * 16 + j) * 4 + r of lane (q, n)
-    //      is source 4 q + r, entry (row n, column j) of bin h: packed position n <= j ? re(n, j) : im(j, n)
+    // ---- the four waves (frame phases) added in float64, fixed order; accumulator m = (h * 17 + grp) * 4 + r of lane (q, n)
+    //      is source 4 q + r, bin h, entry: grp 0 the diagonal n; grp 2 c - 1 / 2 c the real / imaginary part of the pair
+    //      (n, (n + c) mod M), stored under its ordered form (i < j): the imaginary part changes sign when the pair wraps
     float* lds = reinterpret_cast<float*>(ring);
     const int NA = Mv * Mv;
-    constexpr int NACC = 2 * 16 * 4;
+    constexpr int NACC = 2 * 17 * 4;                   // 136: 8 rounds of 16 and one of 8
 #pragma unroll
     for (int r0 = 0; r0 < NACC; r0 += kHmChunk) {
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < kHmChunk; ++a) {
             const int m = r0 + a;       // compile-time
-            lds[a * kHmLdsStride + tid] = acc[m / 64][(m / 4) % 16][m % 4];
+            if (m < NACC) lds[a * kHmLdsStride + tid] = acc[m / 68][(m / 4) % 17][m % 4];
         }
         __syncthreads();
 #pragma unroll
         for (int v = 0; v < kHmChunk * 64 / kBlock; ++v) {
             const int aa = wave + 4 * v;            // the lane is this thread's own
+            const int m = r0 + aa;
+            if (m >= NACC) continue;
             double s = 0.;
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) s += (double)lds[aa * kHmLdsStride + w * 64 + lane];
-            const int m = r0 + aa;
-            const int h = m / 64, j = (m / 4) % 16, r = m % 4;
+            const int h = m / 68, grp = (m / 4) % 17, r = m % 4;
             const int src = 4 * q + r, fo = f0 + h;
-            if (fo < F && src < K && n < Mv && j < Mv) {
-                const int pos = n == j ? n : (n < j ? herm_pair_index(Mv, n, j) : herm_pair_index(Mv, j, n) + 1);
-                Vpart[(((size_t)blockIdx.y * F + fo) * K + src) * NA + pos] = s;
+            if (fo >= F || src >= K || n >= M) continue;
+            int pos;
+            if (grp == 0) {
+                if (n >= Mv) continue;
+                pos = n;
+            } else {
+                const int c = (grp + 1) >> 1, im = (grp + 1) & 1;        // grp 2c-1: re, 2c: im
+                if (c > MH || (c == MH && n >= MH)) continue;             // (c = M/2: the upper half of the lanes repeats the lower)
+                const int mm = (n + c) % M;
+                const int i = n < mm ? n : mm, j = n < mm ? mm : n;
+                if (j >= Mv) continue;
+                pos = herm_pair_index(Mv, i, j) + im;
+                if (im && mm < n) s = -s;                                 // Im(x_i conj x_j) = -Im(x_j conj x_i)
             }
+            Vpart[(((size_t)blockIdx.y * F + fo) * K + src) * NA + pos] = s;
         }
     }
 }
