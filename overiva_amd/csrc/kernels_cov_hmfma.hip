@@ -47,10 +47,14 @@ struct HmOps {
     float2 row;
     float2 x[8];
 };
-template <bool FIRST>
+template <bool FIRST, bool M16>
 __device__ __forceinline__ void hm_read_issue(unsigned base, const unsigned (&ao)[9], unsigned a_w, HmOps& o, float& w) {
     if constexpr (FIRST) {
         asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w), "n"(2 * (kHmStages - 1)) : "memory");
+    }
+    if constexpr (M16) {
+        asm volatile("ds_read_b64 %0, %1" : "=&v"(o.row) : "v"(base + ao[0]) : "memory");
+        return;
     }
     asm volatile(
         "ds_read_b64 %0, %9\n\t"
@@ -74,6 +78,11 @@ __device__ __forceinline__ void hm_read_wait() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// M16: exactly 16 channels -- channel (n + c) mod 16 of the lane's frame sits c lanes further in its 16-lane row, so the
+// partner of every product is a DPP row rotation of the lane's own operand (a modifier of the multiply / FMA itself): one
+// 8-byte LDS read per lane, bin and stage instead of nine (which, four frames hitting the same banks, kept the LDS pipe of
+// the CU busier than the matrix pipes).  Fewer channels: the partners are gathered from LDS.
+template <bool M16>
 __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __restrict__ X, const float* __restrict__ Wt,
                                                               double* __restrict__ Vpart, int T, int F, int M, int Mv, int K, int tc) {
     constexpr int kRingBytes = kWaves * kHmStages * kHmStage;
@@ -130,23 +139,29 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     // the M + 1 groups of one bin: a product (multiply, FMA onto it) and one MFMA with the stage's weights each
     auto groups = [&](const HmOps& o, float w, f32x4 (&a)[17]) {
         a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, o.row.y, o.row.x * o.row.x), a[0], 0, 0, 0);
-#pragma unroll
-        for (int c = 1; c <= 8; ++c) {
-            if (c <= MH) {                                    // (wave-uniform)
-                const float2 x = o.x[c - 1];
+        static_for<8>([&](auto cc) {
+            constexpr int c = decltype(cc)::value + 1;
+            if (M16 || c <= MH) {                             // (wave-uniform)
+                float2 x;
+                if constexpr (M16) {
+                    x.x = dpp<0x120 + 16 - c>(o.row.x);       // row_ror:(16 - c): lane n receives lane (n + c) mod 16
+                    x.y = dpp<0x120 + 16 - c>(o.row.y);
+                } else {
+                    x = o.x[c - 1];
+                }
                 a[2 * c - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, x.y, o.row.x * x.x), a[2 * c - 1], 0, 0, 0);     // Re x_n conj x_m
                 a[2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, x.x, -(o.row.x * x.y)), a[2 * c], 0, 0, 0);         // Im x_n conj x_m
             }
-        }
+        });
     };
     // one stage: both bins; the second bin's operands are read while the first bin's matrix instructions issue
     auto stage = [&](int s) {
         const unsigned so = (unsigned)(s * kHmStage);
         float w, wdummy = 0.f;
         HmOps o0, o1;
-        hm_read_issue<true>(lbase + so, ao, a_w0 + so, o0, w);
+        hm_read_issue<true, M16>(lbase + so, ao, a_w0 + so, o0, w);
         hm_read_wait();
-        hm_read_issue<false>(lbase + so + binoff, ao, 0u, o1, wdummy);
+        hm_read_issue<false, M16>(lbase + so + binoff, ao, 0u, o1, wdummy);
         groups(o0, w, acc[0]);
         hm_read_wait();
         groups(o1, w, acc[1]);
@@ -214,7 +229,8 @@ bool cov_hmfma_supported(int M, int K) { return M >= 10 && M <= 16 && M % 2 == 0
 hipError_t launch_cov_hmfma(hipStream_t s, const float2* X, const float* Wt, double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g) {
     if (!cov_hmfma_supported(M, K) || Mv > M || Mv < M - 1 || Wt == nullptr || g.tc % (4 * kHmFrames) != 0) return hipErrorInvalidValue;
     const dim3 grid((F + 1) / 2, g.nsplit, 1), block(kBlock);
-    return launch_dominant(cov_hmfma_kernel, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+    if (M == 16) return launch_dominant(cov_hmfma_kernel<true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+    return launch_dominant(cov_hmfma_kernel<false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
 }
 
 }  // namespace oiva
