@@ -50,7 +50,11 @@ struct HmOps {
 template <bool FIRST, bool M16>
 __device__ __forceinline__ void hm_read_issue(unsigned base, const unsigned (&ao)[9], unsigned a_w, HmOps& o, float& w) {
     if constexpr (FIRST) {
+#ifdef OIVA_HM_NODMA
+        asm volatile("ds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w) : "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w), "n"(2 * (kHmStages - 1)) : "memory");
+#endif
     }
     if constexpr (M16) {
         asm volatile("ds_read_b64 %0, %1" : "=&v"(o.row) : "v"(base + ao[0]) : "memory");
@@ -141,16 +145,30 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
         a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, o.row.y, o.row.x * o.row.x), a[0], 0, 0, 0);
         static_for<8>([&](auto cc) {
             constexpr int c = decltype(cc)::value + 1;
-            if (M16 || c <= MH) {                             // (wave-uniform)
-                float2 x;
-                if constexpr (M16) {
-                    x.x = dpp<0x120 + 16 - c>(o.row.x);       // row_ror:(16 - c): lane n receives lane (n + c) mod 16
-                    x.y = dpp<0x120 + 16 - c>(o.row.y);
-                } else {
-                    x = o.x[c - 1];
-                }
+            if constexpr (M16) {
+                // the partner channel m = (n + c) mod 16 is the lane's own operand rotated by c lanes inside its 16-lane row
+                // (row_ror:(16 - c): lane n receives lane n + c), as a DPP modifier of the multiply / FMA itself: four vector
+                // instructions per pair of matrix instructions -- on this chip the fp32 matrix instruction runs on the same
+                // ALUs as the vector instructions (measured: their times ADD), so every vector instruction here counts.
+                //   re = fma(row.y, xi_m, row.x * xr_m)          im = fma(row.y, xr_m, -(row.x * xi_m))
+                float re, im;
+                asm("v_mul_f32_dpp %0, %2, %2 row_ror:%4 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_mul_f32_dpp %1, -%3, %2 row_ror:%4 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %0, %3, %3 row_ror:%4 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %1, %2, %3 row_ror:%4 row_mask:0xf bank_mask:0xf"
+                    : "=&v"(re), "=&v"(im)
+                    : "v"(o.row.x), "v"(o.row.y), "n"(16 - c));
+                a[2 * c - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, re, a[2 * c - 1], 0, 0, 0);
+                a[2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, im, a[2 * c], 0, 0, 0);
+            } else if (c <= MH) {                             // (wave-uniform)
+                const float2 x = o.x[c - 1];
+#ifdef OIVA_HM_NOVALU
+                a[2 * c - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, o.row.x, a[2 * c - 1], 0, 0, 0);
+                a[2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, o.row.y, a[2 * c], 0, 0, 0);
+#else
                 a[2 * c - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, x.y, o.row.x * x.x), a[2 * c - 1], 0, 0, 0);     // Re x_n conj x_m
                 a[2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, x.x, -(o.row.x * x.y)), a[2 * c], 0, 0, 0);         // Im x_n conj x_m
+#endif
             }
         });
     };
@@ -171,7 +189,9 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     issue(1, 1);
     issue(2, 2);
     for (int i = 0; i < nstages; ++i) {
+#ifndef OIVA_HM_NODMA
         issue(i + 3, (i + 3) & 3);
+#endif
         stage(i & 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the DMA queue before the ring becomes reduction scratch
