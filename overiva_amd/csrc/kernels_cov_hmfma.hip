@@ -15,11 +15,15 @@
 // select), which is what fits beside a matrix instruction: the pipe takes one every 32 cycles and hides about five issue
 // slots (MI355X_MICROARCH.md).  M + 1 matrix instructions per bin and 4 frames (17 at 16 channels).  The fp32 matrix
 // instruction is an exact fmaf chain in frame order, so the arithmetic class is that of the vector-ALU kernel: float32
-// products, float32 chains of T / (4 nsplit) frames, float64 sums across waves and splits.
+// products, float32 chains of T / (8 nsplit) frames, float64 sums across chains, waves and splits.
 //
-// Geometry and memory exactly as kernels_cov_half16.hip: a workgroup = 2 bins x 4 frame phases (waves), one
-// global_load_lds per wave and stage moves 4 frames x 256 bytes into a 4-stage ring; the 64 weights of a stage (4 frames x
-// 16 sources) ride the same ring by a second, 4-byte DMA whose lane l lands exactly where lane l reads its A operand.
+// Geometry: a workgroup = ONE bin x 4 waves x 2 accumulator sets = 8 frame phases.  A wave's frames are t_begin + wave + 4 n;
+// a stage holds n = 8 i .. 8 i + 7, the first four feeding accumulator set 0 and the last four set 1: two independent
+// float32 chains per wave, so that the chain bound of the arithmetic class needs HALF the frame splits of a kernel with one
+// chain per wave -- half the float64 partials written here and read by the update kernel (2048 x 4000 x 16 / 16: 4 splits,
+// 268 MB, instead of 8 and 537 MB).  One global_load_lds per wave and stage moves 8 frames x 128 bytes into a 4-stage ring;
+// the 128 weights of a stage (8 frames x 16 sources) ride the same ring by two 4-byte DMAs whose lane l lands exactly where
+// lane l reads its A operand.
 #include <cstdint>
 
 #include "oiva_device.h"
@@ -29,20 +33,20 @@ namespace {
 
 constexpr int kHmStages = 4;
 constexpr int kHmFrames = 4;                            // frames per stage of a wave = the contraction of one MFMA
-constexpr int kHmSlot = 256;                            // bytes of 2 bins x (<= 16) channels of one frame
+constexpr int kHmSlot = 256;                            // bytes of two frames (one per accumulator set) x (<= 16) channels, 128 each
 constexpr int kHmX = kHmFrames * kHmSlot;               // 1 KB of X per stage per wave
-constexpr int kHmStage = kHmX + 256;                    // + 64 weights
-constexpr int kHmChunk = 16;
+constexpr int kHmStage = kHmX + 512;                    // + 2 x 64 weights
+constexpr int kHmChunk = 32;                            // accumulators per LDS round of the epilogue: 4 groups x 2 sets x 4 (5 rounds for 17 groups)
 constexpr int kHmLdsStride = kBlock + 1;
 constexpr int kHmWeightStride = 16;                     // row stride of the weight table (launch_cov_weights)
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
-// The lane's operands of one bin of one stage: its own channel n and the channels (n + c) mod M, c = 1 .. 8 (nine 8-byte LDS
-// reads at per-lane addresses) and -- with the first bin -- its weight, with the counted wait for the stage's two DMAs in
-// front.  asm: hipcc drains the whole DMA queue in front of any LDS read it can see.  The reads are ISSUED by one statement
-// and WAITED for by another, so that the second bin's reads fly while the first bin's matrix instructions issue.
+// The lane's operands of one accumulator set of one stage: its own channel n and the channels (n + c) mod M, c = 1 .. 8 (nine
+// 8-byte LDS reads at per-lane addresses) and its weight -- for the first set with the counted wait for the stage's three
+// DMAs in front.  asm: hipcc drains the whole DMA queue in front of any LDS read it can see.  The reads are ISSUED by one
+// statement and WAITED for by another, so that the second set's reads fly while the first set's matrix instructions issue.
 struct HmOps {
     float2 row;
     float2 x[8];
@@ -53,8 +57,10 @@ __device__ __forceinline__ void hm_read_issue(unsigned base, const unsigned (&ao
 #ifdef OIVA_HM_NODMA
         asm volatile("ds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w) : "memory");
 #else
-        asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w), "n"(2 * (kHmStages - 1)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w), "n"(3 * (kHmStages - 1)) : "memory");
 #endif
+    } else {
+        asm volatile("ds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w) : "memory");
     }
     if constexpr (M16) {
         asm volatile("ds_read_b64 %0, %1" : "=&v"(o.row) : "v"(base + ao[0]) : "memory");
@@ -84,26 +90,30 @@ __device__ __forceinline__ void hm_read_wait() {
 
 // M16: exactly 16 channels -- channel (n + c) mod 16 of the lane's frame sits c lanes further in its 16-lane row, so the
 // partner of every product is a DPP row rotation of the lane's own operand (a modifier of the multiply / FMA itself): one
-// 8-byte LDS read per lane, bin and stage instead of nine (which, four frames hitting the same banks, kept the LDS pipe of
+// 8-byte LDS read per lane, set and stage instead of nine (which, four frames hitting the same banks, kept the LDS pipe of
 // the CU busier than the matrix pipes).  Fewer channels: the partners are gathered from LDS.
 template <bool M16>
 __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __restrict__ X, const float* __restrict__ Wt,
                                                               double* __restrict__ Vpart, int T, int F, int M, int Mv, int K, int tc) {
     constexpr int kRingBytes = kWaves * kHmStages * kHmStage;
     constexpr int kScratchBytes = (int)sizeof(float) * kHmChunk * kHmLdsStride;
+#ifdef OIVA_HM_LDSPAD
+    __shared__ float4 ring[72 * 1024 / 16];
+#else
     __shared__ float4 ring[(kRingBytes > kScratchBytes ? kRingBytes : kScratchBytes) / 16 + 1];
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4;                            // frame of the stage (contraction index)
     const int n = lane & 15;                            // A: source | B: row channel i
-    const int f0 = blockIdx.x * 2;
+    const int f0 = blockIdx.x;
     const int t_begin = blockIdx.y * tc;
     const int t_end = min(T, t_begin + tc);
-    const int nstages = (t_end - t_begin + 4 * kHmFrames - 1) / (4 * kHmFrames);
+    const int nstages = (t_end - t_begin + 8 * kHmFrames - 1) / (8 * kHmFrames);
 
-    // [bin of the pair][group]: group 0 = |x_n|^2, 2 c - 1 / 2 c = real / imaginary part of x_n conj(x_(n + c) mod M), c = 1 .. 8;
+    // [accumulator set][group]: group 0 = |x_n|^2, 2 c - 1 / 2 c = real / imaginary part of x_n conj(x_(n + c) mod M), c = 1 .. 8;
     // lane (q, n) holds sources 4 q + r of its entry
     f32x4 acc[2][17];
 #pragma unroll
@@ -112,24 +122,26 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
         for (int j = 0; j < 17; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int MH = M / 2;
 
-    // ---- DMA side (as kernels_cov_half16.hip): lane l moves 16-byte piece l & 15 of frame l >> 4 of the stage; the wave's
-    //      frames are t_begin + wave + 4 n, a stage holds n = 4 i .. 4 i + 3.  The weights of the same 4 frames: lane l moves
-    //      Wt[frame l >> 4][source l & 15] (frames past the split: the zeroed row T of the table).
+    // ---- DMA side: lane l moves 16-byte piece l & 7 of frame slot l >> 4, half (l & 15) >> 3: the half-0 frame of slot q is
+    //      the wave's frame n = 8 i + q, the half-1 frame n = 8 i + 4 + q (16 frames later).  The weights of the same frames:
+    //      lane l moves Wt[frame of slot l >> 4][source l & 15], once per half (frames past the split: the zeroed row T).
     char* wring = reinterpret_cast<char*>(ring) + wave * (kHmStages * kHmStage);       // wave-uniform
-    const int run_pieces = min(2, F - f0) * M / 2;
-    const unsigned piece_off = (unsigned)min(lane & 15, run_pieces - 1) * 16u;
+    const int half = (lane >> 3) & 1;
+    const unsigned piece_off = (unsigned)min(lane & 7, M / 2 - 1) * 16u;
     const char* xbytes = reinterpret_cast<const char*>(X);
     const size_t row_bytes = (size_t)F * M * 8;
     const char* run0 = xbytes + (size_t)f0 * M * 8 + piece_off;
     auto issue = [&](int i, int s) {
-        const int t = t_begin + wave + 4 * (kHmFrames * i + q);
-        const int tcl = min(i < nstages ? t : T - 1, T - 1);
+        const int t0 = t_begin + wave + 4 * (2 * kHmFrames * i + q), t1 = t0 + 4 * kHmFrames;
+        const int tx = half ? t1 : t0;
+        const int tcl = min(i < nstages ? tx : T - 1, T - 1);
         __builtin_amdgcn_global_load_lds((gvoid_t*)(run0 + (size_t)tcl * row_bytes), (lvoid_t*)(wring + s * kHmStage), 16, 0, 0);
-        const int tw = (i < nstages && t < t_end) ? t : T;
-        __builtin_amdgcn_global_load_lds((gvoid_t*)(Wt + (size_t)tw * kHmWeightStride + n), (lvoid_t*)(wring + s * kHmStage + kHmX), 4, 0, 0);
+        const int tw0 = (i < nstages && t0 < t_end) ? t0 : T, tw1 = (i < nstages && t1 < t_end) ? t1 : T;
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(Wt + (size_t)tw0 * kHmWeightStride + n), (lvoid_t*)(wring + s * kHmStage + kHmX), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(Wt + (size_t)tw1 * kHmWeightStride + n), (lvoid_t*)(wring + s * kHmStage + kHmX + 256), 4, 0, 0);
     };
 
-    // ---- operand addresses of this lane inside a frame slot of bin 0 (bin h at + h * M * 8): its own channel, then the
+    // ---- operand addresses of this lane inside a frame slot of set 0 (set 1 at + 128 bytes): its own channel, then the
     //      channels (n + c) mod M; lanes n >= M (fewer than 16 channels) read channel 0 and produce entries that are dropped
     const unsigned lbase = (unsigned)(uintptr_t)wring + (unsigned)(q * kHmSlot);
     const int nn = n < M ? n : 0;
@@ -138,9 +150,10 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
 #pragma unroll
     for (int c = 1; c <= 8; ++c) ao[c] = 8u * (unsigned)((nn + c) % M);
     const unsigned a_w0 = (unsigned)(uintptr_t)wring + (unsigned)kHmX + 4u * (unsigned)lane;
-    const unsigned binoff = (unsigned)(M * 8);
+    const unsigned a_w1 = a_w0 + 256u;
+    constexpr unsigned setoff = 128u;
 
-    // the M + 1 groups of one bin: a product (multiply, FMA onto it) and one MFMA with the stage's weights each
+    // the M + 1 groups of one accumulator set: a product (multiply, FMA onto it) and one MFMA with the stage's weights each
     auto groups = [&](const HmOps& o, float w, f32x4 (&a)[17]) {
         a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, o.row.y, o.row.x * o.row.x), a[0], 0, 0, 0);
         static_for<8>([&](auto cc) {
@@ -172,17 +185,17 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
             }
         });
     };
-    // one stage: both bins; the second bin's operands are read while the first bin's matrix instructions issue
+    // one stage: both sets; the second set's operands are read while the first set's matrix instructions issue
     auto stage = [&](int s) {
         const unsigned so = (unsigned)(s * kHmStage);
-        float w, wdummy = 0.f;
+        float w0, w1;
         HmOps o0, o1;
-        hm_read_issue<true, M16>(lbase + so, ao, a_w0 + so, o0, w);
+        hm_read_issue<true, M16>(lbase + so, ao, a_w0 + so, o0, w0);
         hm_read_wait();
-        hm_read_issue<false, M16>(lbase + so + binoff, ao, 0u, o1, wdummy);
-        groups(o0, w, acc[0]);
+        hm_read_issue<false, M16>(lbase + so + setoff, ao, a_w1 + so, o1, w1);
+        groups(o0, w0, acc[0]);
         hm_read_wait();
-        groups(o1, w, acc[1]);
+        groups(o1, w1, acc[1]);
     };
 
     issue(0, 0);
@@ -196,46 +209,61 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the DMA queue before the ring becomes reduction scratch
 
-    // ---- the four waves (frame phases) added in float64, fixed order; accumulator m = (h * 17 + grp) * 4 + r of lane (q, n)
-    //      is source 4 q + r, bin h, entry: grp 0 the diagonal n; grp 2 c - 1 / 2 c the real / imaginary part of the pair
-    //      (n, (n + c) mod M), stored under its ordered form (i < j): the imaginary part changes sign when the pair wraps
+    // ---- the eight chains (4 waves x 2 sets) added in float64, fixed order; accumulator r of group grp of lane (q, n) is
+    //      source 4 q + r, entry: grp 0 the diagonal n; grp 2 c - 1 / 2 c the real / imaginary part of the pair
+    //      (n, (n + c) mod M), stored under its ordered form (i < j): the imaginary part changes sign when the pair wraps.
+    //      A round = 4 groups; wave w adds the eight values of accumulator r = w of each, so that group, pair distance and
+    //      re / im are compile-time and only (source row, channel) come from the lane.
     float* lds = reinterpret_cast<float*>(ring);
     const int NA = Mv * Mv;
-    constexpr int NACC = 2 * 17 * 4;                   // 136: 8 rounds of 16 and one of 8
+#ifdef OIVA_HM_NOEPI
+    {
+        float t = 0.f;
+        for (int h = 0; h < 2; ++h) for (int g2 = 0; g2 < 17; ++g2) for (int r = 0; r < 4; ++r) t += acc[h][g2][r];
+        if (t == 1.2345e30f) Vpart[tid] = t;
+        return;
+    }
+#endif
+    double* vout = Vpart + (((size_t)blockIdx.y * F + f0) * K + 4 * q + wave) * NA;
+    const bool live = 4 * q + wave < K && n < M;
 #pragma unroll
-    for (int r0 = 0; r0 < NACC; r0 += kHmChunk) {
+    for (int g0 = 0; g0 < 17; g0 += 4) {
         __syncthreads();
 #pragma unroll
-        for (int a = 0; a < kHmChunk; ++a) {
-            const int m = r0 + a;       // compile-time
-            if (m < NACC) lds[a * kHmLdsStride + tid] = acc[m / 68][(m / 4) % 17][m % 4];
-        }
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (g0 + v < 17) lds[((v * 4 + r) * 2 + h) * kHmLdsStride + tid] = acc[h][g0 + v][r];
         __syncthreads();
 #pragma unroll
-        for (int v = 0; v < kHmChunk * 64 / kBlock; ++v) {
-            const int aa = wave + 4 * v;            // the lane is this thread's own
-            const int m = r0 + aa;
-            if (m >= NACC) continue;
+        for (int v = 0; v < 4; ++v) {
+            const int grp = g0 + v;                 // compile-time
+            if (grp >= 17) continue;
+            const int c = (grp + 1) >> 1, im = (grp + 1) & 1;            // grp 2c-1: re, 2c: im   (grp 0: the diagonal)
             double s = 0.;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) s += (double)lds[aa * kHmLdsStride + w * 64 + lane];
-            const int h = m / 68, grp = (m / 4) % 17, r = m % 4;
-            const int src = 4 * q + r, fo = f0 + h;
-            if (fo >= F || src >= K || n >= M) continue;
+            for (int w = 0; w < kWaves; ++w)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) s += (double)lds[((v * 4 + wave) * 2 + h) * kHmLdsStride + w * 64 + lane];
+            if (!live) continue;
             int pos;
             if (grp == 0) {
                 if (n >= Mv) continue;
                 pos = n;
             } else {
-                const int c = (grp + 1) >> 1, im = (grp + 1) & 1;        // grp 2c-1: re, 2c: im
                 if (c > MH || (c == MH && n >= MH)) continue;             // (c = M/2: the upper half of the lanes repeats the lower)
-                const int mm = (n + c) % M;
+                const int mm = n + c >= M ? n + c - M : n + c;
                 const int i = n < mm ? n : mm, j = n < mm ? mm : n;
                 if (j >= Mv) continue;
                 pos = herm_pair_index(Mv, i, j) + im;
                 if (im && mm < n) s = -s;                                 // Im(x_i conj x_j) = -Im(x_j conj x_i)
             }
-            Vpart[(((size_t)blockIdx.y * F + fo) * K + src) * NA + pos] = s;
+#ifdef OIVA_HM_NOSTORE
+            if (s == 1.2345e300)
+#endif
+            vout[pos] = s;
         }
     }
 }
@@ -247,8 +275,8 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
 bool cov_hmfma_supported(int M, int K) { return M >= 10 && M <= 16 && M % 2 == 0 && K >= 9 && K <= 16; }
 
 hipError_t launch_cov_hmfma(hipStream_t s, const float2* X, const float* Wt, double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g) {
-    if (!cov_hmfma_supported(M, K) || Mv > M || Mv < M - 1 || Wt == nullptr || g.tc % (4 * kHmFrames) != 0) return hipErrorInvalidValue;
-    const dim3 grid((F + 1) / 2, g.nsplit, 1), block(kBlock);
+    if (!cov_hmfma_supported(M, K) || Mv > M || Mv < M - 1 || Wt == nullptr || g.tc % (8 * kHmFrames) != 0) return hipErrorInvalidValue;
+    const dim3 grid(F, g.nsplit, 1), block(kBlock);
     if (M == 16) return launch_dominant(cov_hmfma_kernel<true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
     return launch_dominant(cov_hmfma_kernel<false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
 }

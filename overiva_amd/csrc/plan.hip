@@ -212,11 +212,14 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         if (nsplit <= 0) {
             // (float64: no chain to bound; the four-source form runs a little faster in two rounds of workgroups -- 2048 x 4000
             //  x 16 / 4: 1 split 744 us, 2 splits 691, 4 splits 693; the eight-source form does not care)
-            nsplit = p->cov_f64() ? (g.kc == 4 && p->T >= 1024 ? 2 : 1) : ceil_div(p->T, p->upd_f64() ? 512 : 1024);
-            const int per_cu = p->cov_f64() && g.kc == 4 ? 4 : 2;      // workgroups a CU holds (launch bounds of the kernels)
-            while (g.nbg * ceil_div(p->K, g.kc) * nsplit < per_cu * p->n_cu && ceil_div(p->T, nsplit + 1) >= 64) ++nsplit;
+            // (the matrix-core kernel: one bin per workgroup and eight float32 chains -- half the splits for the same chain)
+            const int chains = g.hmfma ? 8 : 4;
+            nsplit = p->cov_f64() ? (g.kc == 4 && p->T >= 1024 ? 2 : 1) : ceil_div(p->T, chains * (p->upd_f64() ? 128 : 256));
+            const int per_cu = g.hmfma ? 3 : p->cov_f64() && g.kc == 4 ? 4 : 2;      // workgroups a CU holds (registers / launch bounds)
+            const int groups = g.hmfma ? p->F : g.nbg * ceil_div(p->K, g.kc);
+            while (groups * nsplit < per_cu * p->n_cu && ceil_div(p->T, nsplit + 1) >= 64) ++nsplit;
         }
-        g.tc = round_up(ceil_div(p->T, nsplit), 16);
+        g.tc = round_up(ceil_div(p->T, nsplit), g.hmfma ? 32 : 16);
         g.nsplit = ceil_div(p->T, g.tc);
         p->cov = g;
         return;

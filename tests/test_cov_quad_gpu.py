@@ -216,11 +216,12 @@ def test_16_channels_2_sources_full_size_properties(oa, mode):
 @pytest.mark.parametrize("shape", [(400, 6, 16, 16), (333, 5, 16, 9), (250, 3, 12, 12), (200, 4, 14, 11), (180, 3, 15, 15), (170, 2, 11, 10)])
 def test_sources_on_the_matrix_cores_against_the_vector_alu_kernel(oa, shape):
     """9..16 sources: the weighted sums of all sources as one small GEMM per bin on the fp32 matrix cores
-    (csrc/kernels_cov_hmfma.hip), the Hermitian products formed along the cyclic diagonals of the matrix.  The fp32 matrix
-    instruction is an exact fmaf chain in frame order and the real parts are rounded as the vector-ALU kernel rounds them;
-    the imaginary parts round the other product of the pair first, so the two kernels agree to a few float32 roundings of a
-    product -- and both sit within the single-pass bound of the oracle.  Ragged shapes: odd channel counts (padded copy of
-    X), fewer than 16 channels / sources, bins and frames that do not fill the last workgroup."""
+    (csrc/kernels_cov_hmfma.hip), the Hermitian products formed along the cyclic diagonals of the matrix.  Same arithmetic
+    class as the vector-ALU kernel -- float32 products, float32 chains (the fp32 matrix instruction is an fmaf chain in frame
+    order), float64 sums across chains and splits -- with the frames dealt to the chains differently (eight chains per
+    workgroup and half the splits), so the two kernels agree to a few float32 roundings and both sit within the single-pass
+    bound of the oracle.  Ragged shapes: odd channel counts (padded copy of X), fewer than 16 channels / sources, frames that
+    do not fill the last stage."""
     T, F, M, K = shape
     X = orc.synth_iid(T, F, M, seed=31)
     rinv = np.random.default_rng(5).gamma(2.0, 1.0, (T, K)).astype(np.float32)
@@ -235,6 +236,5 @@ def test_sources_on_the_matrix_cores_against_the_vector_alu_kernel(oa, shape):
             p.t_run_weighted_cov()
             V[on] = p.t_get_v(np.complex128)
     ref = orc.weighted_cov_all(X, rinv.astype(np.float64))
-    assert np.array_equal(V[True].real, V[False].real)
     assert orc.rel_err(V[True], V[False]) < 3e-7
     assert orc.rel_err(V[True], ref) < 3e-6 and orc.rel_err(V[False], ref) < 3e-6
