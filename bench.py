@@ -240,6 +240,29 @@ def _cov_roofline(shape, mode, cov_ms):
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
                        "note": "co-limited by the vector ALU: 512 real FMAs per (bin, frame, source pair) at 16 channels against 128 at 8"}
+    mc = m + m % 2
+    if mode != "precise" and k >= 9 and mc >= 10 and os.environ.get("OIVA_COV_HMFMA", "1") != "0":
+        # the sources on the fp32 matrix cores (csrc/kernels_cov_hmfma.hip): per bin and 4 frames mc + 1 v_mfma_f32_16x16x4_f32
+        # (2048 flops each, all 16 source rows whatever k) and 2 + 4 (mc / 2) vector instructions forming the Hermitian products
+        # (64 lanes x 2 flop slots); bound by fp32 arithmetic -- matrix and vector instructions share the 157.3 TFLOP/s ALUs
+        bytes_cov = cov_algorithmic_bytes(t, f, m, k)
+        mfma = (mc + 1) * 2048.0 / 4 * t * f
+        valu = (2 + 4 * (mc // 2)) * 128.0 / 4 * t * f
+        issued = mfma + valu
+        useful = ((m * (m - 1) // 2) * (6.0 + 4.0 * k) + m * (3.0 + 2.0 * k)) * t * f     # Hermitian half, products formed once
+        naive = 8.0 * k * m * m * t * f                         # naive complex count (268.4 GF at 16 x 16)
+        sec = cov_ms * 1e-3
+        kname = f"cov_hmfma_kernel<{'true' if mc == 16 else 'false'}>"
+        return kname, {"bound": "fp32", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, the sources on the fp32 matrix cores, overiva.py:179)",
+                       "achieved": issued / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                       "issued_flops_per_launch": issued, "issued_matrix_flops_per_launch": mfma, "issued_vector_flops_per_launch": valu,
+                       "useful_flops_per_launch": useful, "naive_complex_flops_per_launch": naive,
+                       "useful_tflops": useful / sec / 1e12, "frac_useful": useful / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                       "naive_complex_tflops": naive / sec / 1e12, "frac_naive": naive / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                       "algorithmic_bytes_per_launch": bytes_cov, "hbm_gbs": bytes_cov / sec / 1e9, "avg_launch_ms": cov_ms, "traffic": None,
+                       "note": "achieved / frac count ISSUED flops (matrix instructions 2048 each, vector instructions 128) against the 157.3 "
+                               "TFLOP/s spec peak, which on CDNA4 the fp32 matrix and vector instructions SHARE (measured: their times add); "
+                               "useful = Hermitian half with each product formed once; naive = SURVEY 8d's 8 K M^2 T F"}
     if mode != "precise" and k > 4:
         # the Hermitian half on the vector ALU, 32 lanes per (bin, frame), every source in one pass: bound by fp32 arithmetic
         # (cfg5's roofline is the 157.3 TFLOP/s fp32 peak, which the packed vector ALU shares with the matrix cores)

@@ -37,10 +37,11 @@ for c in "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i + 1))
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_precise/p$i" -o p -- $B $HEAD --precision precise > /dev/null 2>&1
 done
-# counters, cfg5 (default arithmetic: the 32-lanes-per-(bin, frame) vector-ALU covariance kernel)
+# counters, cfg5 (default arithmetic: the covariance kernel with the sources on the fp32 matrix cores)
 i=0
 for c in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
-         "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
+         "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS" "FETCH_SIZE" "WRITE_SIZE" \
+         "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT"; do
     i=$((i + 1))
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_cfg5/p$i" -o p -- $B --config cfg5 $HEAD > /dev/null 2>&1
 done
@@ -68,6 +69,7 @@ python3 $ROOT/tools/launch_cost.py > "$OUT/launch_cost.log" 2>&1
 python3 $ROOT/tools/exp_resident_trace.py 4000 256 8 2 20 mixed > "$OUT/resident_trace_shard8.log" 2>&1
 python3 $ROOT/tools/exp_resident_trace.py 4000 256 8 2 20 mixed 8 > "$OUT/resident_trace_shard8_loopback8.log" 2>&1
 python3 $ROOT/tools/res_ab.py > "$OUT/resident_configs.log" 2>&1
+python3 $ROOT/tools/cfg5_cov_sweep.py > "$OUT/cfg5_cov_sweep.log" 2>&1
 # keep what travels back small: drop the raw kernel traces of the --stats runs
 find "$OUT" -name "*_kernel_trace.csv" -path "*stats_*" -delete
 find "$OUT" -name "*_agent_info.csv" -delete
