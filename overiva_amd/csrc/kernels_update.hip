@@ -360,11 +360,11 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Structured form of the same update for 1 or 2 sources with background channels (K < M): the chain that
+// Structured form of the same update for 1 .. 3 sources with background channels (K < M; the chain itself also takes 4): the chain that
 // depends on W is a K x K solve and a few matrix-vector products instead of an M x M elimination with pivoting.
 //   W_hat^H = [[W^H], [J^H | -I]],  A = W_hat^H V,  A w = e_s   <=>   W_hat^H u = e_s,  u = V w:
 //     rows >= K :  u_bot = J^H u_top
-//     rows <  K :  Q u_top = e_s   with   Q = B_tt + B_tb B_bt   (B = W_hat^H in K | M-K blocks)      K x K
+//     rows <  K :  Q u_top = e_s   with   Q = B_tt + B_tb B_bt   (B = W_hat^H in K | M-K blocks)      K x K, by cofactors
 //     w = V^-1 u                   V^-1 of the Hermitian positive definite V_s needs no pivoting and does not
 //                                  depend on W: all K inverses are formed before the chain starts
 //   w /= sqrt(w^H V w)  (overiva.py:185-186);  J from (W^H Cx)[:, :K]^-1 (W^H Cx)[:, K:] in closed form (:96-98).
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <int MP, typename R, int MT, int KT>
 __global__ __launch_bounds__(kBlock) void update_bg_kernel(UpdateArgs a) {
-    static_assert(KT == 1 || KT == 2, "closed-form K x K solves");
+    static_assert(KT >= 1 && KT <= 4, "closed-form K x K solves");
     constexpr int G = MP * MP;
     constexpr int K = KT;
     const int tid = threadIdx.x;
@@ -452,12 +452,17 @@ hipError_t launch_bg_one(hipStream_t s, const UpdateArgs& a) {
 // sweeps use (overiva_sim_config.json: 2..8 microphones, 1..4 targets, determined AuxIVA): 1, 2, 3, 4, MT
 template <int MP, int MT>
 hipError_t launch_sq_m(hipStream_t s, const UpdateArgs& a) {
-    // 1 or 2 sources with background channels: the structured chain (the J initialisation of the prologue keeps
+    // 1 .. 3 sources with background channels: the structured chain (the J initialisation of the prologue keeps
     // the generic kernel)
     if constexpr (MP >= 4) {
         if (!a.init_only && a.K < MT) {
             if (a.K == 2) return launch_bg_one<MP, MT, 2>(s, a);
             if (a.K == 1) return launch_bg_one<MP, MT, 1>(s, a);
+            // (three sources: the 3 x 3 solves by cofactors, every lane computing all of them -- 2049 x 235, float64: 8 / 3 29.4 ->
+            //  25.8 us, 7 / 3 28.1 -> 22.6.  Four sources the same way measured SLOWER than the pivoting elimination over the
+            //  lanes -- 8 / 4 39.2 -> 44.3 us, 6 / 4 37.8 -> 39.8: the redundant 4 x 4 cofactors cost what they save -- and keep
+            //  the generic kernel.)
+            if constexpr (MT > 3) if (a.K == 3) return launch_bg_one<MP, MT, 3>(s, a);
         }
     }
     if (a.K == MT) return launch_sq_one<MP, MT, MT>(s, a);
