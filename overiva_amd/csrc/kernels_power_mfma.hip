@@ -160,6 +160,11 @@ static hipError_t launch_shape(hipStream_t s, const float2* X, const float2* Wha
 }
 
 hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int M, int Mp, int K) {
+    // (round 4, VERDICT r03 5(i): X AND W through a global_load_lds ring -- one bin per stage, 2 tiles, 2 or 3 stages, 8-12
+    //  waves per CU, no load result held in registers, counted vmcnt waits only -- measured on one box: 254-258 us against
+    //  252 for this kernel; the same loop without the matrix instructions 208-219 us, without the DMAs 140-148 us; whole
+    //  128-byte lines per DMA instruction, no W traffic, the four waves on adjacent bins: all within 201-232 us memory-only.
+    //  The stream of 128-byte runs 262 KB apart is the limit, not the registers.  Dropped.)
     // measured at 2048 x 4000 x 16 / 16 (tiles x bins per group): 4x1 252 us, 2x1 252, 2x2 267, 1x2 279, 1x4 306 -- the
     // W operands come from L2 once per wave and bin, so more frames per wave is less W traffic (W-only 81 us at 1x4);
     // X alone streams in 199 us, the MFMAs alone take 134 us
