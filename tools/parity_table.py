@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the JSON-lines log of tests/test_gpu_parity.py ($OIVA_PARITY_LOG) into the markdown table committed
-under profiles/.   python tools/parity_table.py gpurun_out/parity.jsonl > profiles/r03_parity_errors.md"""
+under profiles/.   python tools/parity_table.py gpurun_out/parity.jsonl > profiles/r04_parity_errors.md"""
 import json
 import sys
 
@@ -11,7 +11,7 @@ def f(x):
 
 rows = [json.loads(line) for line in open(sys.argv[1])]
 e2e = [r for r in rows if r["test"] == "e2e"]
-print("# Achieved parity errors (MI355X, round 3)\n")
+print("# Achieved parity errors (MI355X, round 4)\n")
 print("Source: `tests/test_gpu_parity.py` run with `OIVA_PARITY_LOG` on the GPU box; distances are relative Frobenius")
 print("norms.  `floor` = distance between the REAL reference's complex64 and complex128 results on the fixture")
 print("(stored by `tests/golden/make_golden.py`); `amp` = the reference's own amplification of a 1e-12 input")
