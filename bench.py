@@ -286,6 +286,23 @@ def _cov_roofline(shape, mode, cov_ms):
                                "peak on CDNA4; the planar matrix-core form needs 2.8x the multiply-adds and measured 1.69 ms at 16 x 16); useful = "
                                "Hermitian half with each product formed once; naive = SURVEY 8d's 8 K M^2 T F.  Self-measured issue ceiling, for "
                                f"orientation only: 2.0 ns per packed instruction and SIMD (tools/pkbench.hip) = {floor_ms:.3f} ms for this launch"}
+    if mode == "precise" and k >= 9 and mc == 16 and os.environ.get("OIVA_COV_HMFMA", "1") != "0":
+        # the sources on the fp64 matrix cores (cov_hmfma64_kernel): 17 v_mfma_f64_16x16x4_f64 per bin and 4 frames + 2 + 8 x 6
+        # float64 vector instructions (conversions, products) per lane; fp64 matrix peak = fp64 vector peak = 78.6 TFLOP/s
+        bytes_cov = cov_algorithmic_bytes(t, f, m, k)
+        mfma = 17 * 2048.0 / 4 * t * f
+        valu = (2 + 4 * 8) * 128.0 / 4 * t * f                  # float64 multiplies / FMAs (conversions and moves not counted)
+        issued = mfma + valu
+        naive = 8.0 * k * m * m * t * f
+        sec = cov_ms * 1e-3
+        kname = "cov_hmfma64_kernel"
+        return kname, {"bound": "fp64", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, float64, the sources on the fp64 matrix cores, overiva.py:179)",
+                       "achieved": issued / sec / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                       "issued_flops_per_launch": issued, "issued_matrix_flops_per_launch": mfma, "issued_vector_flops_per_launch": valu,
+                       "naive_complex_flops_per_launch": naive, "naive_complex_tflops": naive / sec / 1e12,
+                       "algorithmic_bytes_per_launch": bytes_cov, "hbm_gbs": bytes_cov / sec / 1e9, "avg_launch_ms": cov_ms, "traffic": None,
+                       "note": "issued float64 flops (matrix instructions 2048 each, vector multiplies / FMAs 128) against the 78.6 TFLOP/s fp64 peak "
+                               "(matrix = vector on MI355X); the float64 vector-ALU kernel it replaces at 9..16 sources measured 2.04 ms at 16 x 16"}
     if mode == "precise" and k >= 3:
         # the same lanes with float64 sums of exact products, four or eight sources per pass: bound by the float64 rate of the
         # vector ALU (14 conversions + 20 + 10 * sources float64 instructions per lane and frame); peak: 78.6 TFLOP/s fp64 vector

@@ -466,11 +466,12 @@ int cov_half16_f64_sources_per_pass(int K) { return K <= 4 ? 4 : 8; }
 
 hipError_t launch_cov_half16_f64(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                                  double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g) {
-    if (!cov_half16_f64_supported(M, K) || Mv > M || Mv < M - 1 || R == nullptr || Wt == nullptr || g.tc % (4 * kH16Frames) != 0) return hipErrorInvalidValue;
+    if (!cov_half16_f64_supported(M, K) || Mv > M || Mv < M - 1 || R == nullptr || Wt == nullptr || (!g.hmfma && g.tc % (4 * kH16Frames) != 0)) return hipErrorInvalidValue;
     double* wt = reinterpret_cast<double*>(Wt);
     h64_weights_kernel<<<dim3(((T + 1) * kH64WeightStride + kBlock - 1) / kBlock), dim3(kBlock), 0, s>>>(R, wt, wscale, model, raw, T, K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (g.hmfma && cov_hmfma64_supported(M, K)) return launch_cov_hmfma64(s, X, wt, Vpart, T, F, M, Mv, K, g);
     const int ns = cov_half16_f64_sources_per_pass(K);
     const dim3 grid((F + 1) / 2, g.nsplit, (K + ns - 1) / ns);
     if (ns == 4) return launch_dominant(cov_half16f64_kernel<4>, grid, dim3(kBlock), 0, s, X, (const double*)wt, Vpart, T, F, M, Mv, K, g.tc);

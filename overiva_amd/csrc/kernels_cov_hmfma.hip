@@ -27,6 +27,7 @@
 #include <cstdint>
 
 #include "oiva_device.h"
+#include "cov_arith.h"
 
 namespace oiva {
 namespace {
@@ -268,11 +269,154 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The `precise` arithmetic (float64 sums of exact float64 products) on the fp64 matrix cores, 16 channels, 9..16 sources:
+// the same GEMM per bin with v_mfma_f64_16x16x4_f64 (A = the float64 weights, B = the products, formed in float64 from the
+// lane's own sample and the DPP-rotated partner: two moves, two conversions, four float64 instructions per pair of matrix
+// instructions).  One accumulator set (no chain to bound); the 8 frames of a stage go into it one half after the other.
+// Weights: the float64 table of kernels_cov_half16.hip, (T + 1, 16) doubles, row T zero -- a lane's weight arrives as two
+// 4-byte DMAs (low and high word, 256 bytes apart) and is read back by one ds_read2_b32.
+// C/D layout of the float64 instruction: lane (q, n), register r = source q + 4 r (not the float32 map).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kHm64Stage = kHmX + 1024;                 // + 2 halves x (low, high) x 64 words
+constexpr int kHm64Chunk = 16;                          // doubles per LDS round of the epilogue: 4 groups x 4
+
+__global__ __launch_bounds__(kBlock, 2) void cov_hmfma64_kernel(const float2* __restrict__ X, const double* __restrict__ Wt,
+                                                                double* __restrict__ Vpart, int T, int F, int Mv, int K, int tc) {
+    constexpr int M = 16, MH = 8;
+    constexpr int kRingBytes = kWaves * kHmStages * kHm64Stage;
+    constexpr int kScratchBytes = (int)sizeof(double) * kHm64Chunk * kHmLdsStride;
+    __shared__ float4 ring[(kRingBytes > kScratchBytes ? kRingBytes : kScratchBytes) / 16 + 1];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4;
+    const int n = lane & 15;
+    const int f0 = blockIdx.x;
+    const int t_begin = blockIdx.y * tc;
+    const int t_end = min(T, t_begin + tc);
+    const int nstages = (t_end - t_begin + 8 * kHmFrames - 1) / (8 * kHmFrames);
+
+    f64x4 acc[17];
+#pragma unroll
+    for (int j = 0; j < 17; ++j) acc[j] = f64x4{0., 0., 0., 0.};
+
+    char* wring = reinterpret_cast<char*>(ring) + wave * (kHmStages * kHm64Stage);       // wave-uniform
+    const int half = (lane >> 3) & 1;
+    const char* run0 = reinterpret_cast<const char*>(X) + (size_t)f0 * M * 8 + (unsigned)(lane & 7) * 16u;
+    const size_t row_bytes = (size_t)F * M * 8;
+    const float* wt32 = reinterpret_cast<const float*>(Wt);
+    auto issue = [&](int i, int s) {
+        const int t0 = t_begin + wave + 4 * (2 * kHmFrames * i + q), t1 = t0 + 4 * kHmFrames;
+        const int tx = half ? t1 : t0;
+        const int tcl = min(i < nstages ? tx : T - 1, T - 1);
+        char* dst = wring + s * kHm64Stage;
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(run0 + (size_t)tcl * row_bytes), (lvoid_t*)dst, 16, 0, 0);
+        const int tw0 = (i < nstages && t0 < t_end) ? t0 : T, tw1 = (i < nstages && t1 < t_end) ? t1 : T;
+        const float* w0 = wt32 + ((size_t)tw0 * kHmWeightStride + n) * 2;
+        const float* w1 = wt32 + ((size_t)tw1 * kHmWeightStride + n) * 2;
+        __builtin_amdgcn_global_load_lds((gvoid_t*)w0, (lvoid_t*)(dst + kHmX), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(w0 + 1), (lvoid_t*)(dst + kHmX + 256), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gvoid_t*)w1, (lvoid_t*)(dst + kHmX + 512), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gvoid_t*)(w1 + 1), (lvoid_t*)(dst + kHmX + 768), 4, 0, 0);
+    };
+    const unsigned a_x = (unsigned)(uintptr_t)wring + (unsigned)(q * kHmSlot + 8 * n);
+    const unsigned a_w = (unsigned)(uintptr_t)wring + (unsigned)kHmX + 4u * (unsigned)lane;
+
+    auto groups = [&](v2f row, double w) {
+        const double xr = (double)row.x, xi = (double)row.y;
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, fma(xi, xi, xr * xr), acc[0], 0, 0, 0);
+        static_for<8>([&](auto cc) {
+            constexpr int c = decltype(cc)::value + 1;
+            // row_ror:(16 - c): lane n receives lane n + c
+            const double pr = (double)dpp<0x120 + 16 - c>(row.x), pi = (double)dpp<0x120 + 16 - c>(row.y);
+            acc[2 * c - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, fma(xi, pi, xr * pr), acc[2 * c - 1], 0, 0, 0);     // Re x_n conj x_m
+            acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, fma(xi, pr, -(xr * pi)), acc[2 * c], 0, 0, 0);           // Im x_n conj x_m
+        });
+    };
+    auto stage = [&](int s) {
+        const unsigned so = (unsigned)(s * kHm64Stage);
+        v2f r0, r1;
+        double w0, w1;
+        asm volatile("s_waitcnt vmcnt(%4)\n\t"
+                     "ds_read_b64 %0, %5\n\t"
+                     "ds_read2_b32 %2, %6 offset1:64\n\t"
+                     "ds_read_b64 %1, %5 offset:128\n\t"
+                     "ds_read2_b32 %3, %6 offset0:128 offset1:192\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(w0), "=&v"(w1)
+                     : "n"(5 * (kHmStages - 1)), "v"(a_x + so), "v"(a_w + so)
+                     : "memory");
+        groups(r0, w0);
+        groups(r1, w1);
+    };
+
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
+    for (int i = 0; i < nstages; ++i) {
+        issue(i + 3, (i + 3) & 3);
+        stage(i & 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the DMA queue before the ring becomes reduction scratch
+
+    // ---- the four waves added in fixed order; register r of group grp of lane (q, n) is source q + 4 r, entry as in the
+    //      float32 kernel.  A round = 4 groups; wave w adds the four values of register r = w of each.
+    double* lds = reinterpret_cast<double*>(ring);
+    const int NA = Mv * Mv;
+    const int src = q + 4 * wave;
+    double* vout = Vpart + (((size_t)blockIdx.y * F + f0) * K + src) * NA;
+    const bool live = src < K;
+#pragma unroll
+    for (int g0 = 0; g0 < 17; g0 += 4) {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (g0 + v < 17) lds[(v * 4 + r) * kHmLdsStride + tid] = acc[g0 + v][r];
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int grp = g0 + v;                 // compile-time
+            if (grp >= 17) continue;
+            const int c = (grp + 1) >> 1, im = (grp + 1) & 1;            // grp 2c-1: re, 2c: im   (grp 0: the diagonal)
+            double s = 0.;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) s += lds[(v * 4 + wave) * kHmLdsStride + w * 64 + lane];
+            if (!live) continue;
+            int pos;
+            if (grp == 0) {
+                if (n >= Mv) continue;
+                pos = n;
+            } else {
+                if (c == MH && n >= MH) continue;                          // (c = M/2: the upper half of the lanes repeats the lower)
+                const int mm = n + c >= M ? n + c - M : n + c;
+                const int i = n < mm ? n : mm, j = n < mm ? mm : n;
+                if (j >= Mv) continue;
+                pos = herm_pair_index(Mv, i, j) + im;
+                if (im && mm < n) s = -s;                                 // Im(x_i conj x_j) = -Im(x_j conj x_i)
+            }
+            vout[pos] = s;
+        }
+    }
+}
+
 }  // namespace
 
 // 9..16 sources on 10/12/14/16 channels (odd counts: the padded copy of X).  Wt: the (T + 1, 16) table of final weights of
 // launch_cov_weights, row T zeroed (kernels_cov_half16.hip fills it and calls this).
 bool cov_hmfma_supported(int M, int K) { return M >= 10 && M <= 16 && M % 2 == 0 && K >= 9 && K <= 16; }
+
+// float64 sums (`precise`): exactly 16 channels (15: the padded copy of X), 9..16 sources.  Wt: the (T + 1, 16) table of float64
+// weights of kernels_cov_half16.hip (h64_weights_kernel), row T zero.
+bool cov_hmfma64_supported(int M, int K) { return M == 16 && K >= 9 && K <= 16; }
+
+hipError_t launch_cov_hmfma64(hipStream_t s, const float2* X, const double* Wt, double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g) {
+    if (!cov_hmfma64_supported(M, K) || Mv > M || Mv < M - 1 || Wt == nullptr || g.tc % (8 * kHmFrames) != 0) return hipErrorInvalidValue;
+    return launch_dominant(cov_hmfma64_kernel, dim3(F, g.nsplit, 1), dim3(kBlock), 0, s, X, Wt, Vpart, T, F, Mv, K, g.tc);
+}
 
 hipError_t launch_cov_hmfma(hipStream_t s, const float2* X, const float* Wt, double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g) {
     if (!cov_hmfma_supported(M, K) || Mv > M || Mv < M - 1 || Wt == nullptr || g.tc % (8 * kHmFrames) != 0) return hipErrorInvalidValue;

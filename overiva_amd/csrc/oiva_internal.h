@@ -133,6 +133,8 @@ hipError_t launch_cov_half16(hipStream_t s, const float2* X, const float* R, flo
 // 9..16 sources: the sources as rows of the fp32 matrix-core instruction, Hermitian products on the vector ALU (kernels_cov_hmfma.hip)
 bool cov_hmfma_supported(int M, int K);
 hipError_t launch_cov_hmfma(hipStream_t s, const float2* X, const float* Wt, double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g);
+bool cov_hmfma64_supported(int M, int K);
+hipError_t launch_cov_hmfma64(hipStream_t s, const float2* X, const double* Wt, double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g);
 bool cov_half16_f64_supported(int M, int K);
 int cov_half16_f64_sources_per_pass(int K);
 hipError_t launch_cov_half16_f64(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,

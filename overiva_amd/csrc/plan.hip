@@ -206,7 +206,7 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     if (p->M > 8 && p->cov_quad_on &&
         (p->cov_f64() ? cov_half16_f64_supported(Mc, p->K) : p->K > 4 && cov_half16_supported(Mc, p->K))) {
         g.half16 = 1;
-        g.hmfma = (!p->cov_f64() && p->cov_hmfma_on && cov_hmfma_supported(Mc, p->K)) ? 1 : 0;
+        g.hmfma = (p->cov_hmfma_on && (p->cov_f64() ? cov_hmfma64_supported(Mc, p->K) : cov_hmfma_supported(Mc, p->K))) ? 1 : 0;
         g.nbg = ceil_div(p->F, 2);
         g.kc = p->cov_f64() ? cov_half16_f64_sources_per_pass(p->K) : cov_half16_sources_per_pass(p->K);
         if (nsplit <= 0) {
@@ -214,8 +214,8 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
             //  x 16 / 4: 1 split 744 us, 2 splits 691, 4 splits 693; the eight-source form does not care)
             // (the matrix-core kernel: one bin per workgroup and eight float32 chains -- half the splits for the same chain)
             const int chains = g.hmfma ? 8 : 4;
-            nsplit = p->cov_f64() ? (g.kc == 4 && p->T >= 1024 ? 2 : 1) : ceil_div(p->T, chains * (p->upd_f64() ? 128 : 256));
-            const int per_cu = g.hmfma ? 3 : p->cov_f64() && g.kc == 4 ? 4 : 2;      // workgroups a CU holds (registers / launch bounds)
+            nsplit = p->cov_f64() ? (!g.hmfma && g.kc == 4 && p->T >= 1024 ? 2 : 1) : ceil_div(p->T, chains * (p->upd_f64() ? 128 : 256));
+            const int per_cu = g.hmfma ? (p->cov_f64() ? 2 : 3) : p->cov_f64() && g.kc == 4 ? 4 : 2;      // workgroups a CU holds (registers / launch bounds)
             const int groups = g.hmfma ? p->F : g.nbg * ceil_div(p->K, g.kc);
             while (groups * nsplit < per_cu * p->n_cu && ceil_div(p->T, nsplit + 1) >= 64) ++nsplit;
         }

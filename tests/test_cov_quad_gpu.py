@@ -238,3 +238,28 @@ def test_sources_on_the_matrix_cores_against_the_vector_alu_kernel(oa, shape):
     ref = orc.weighted_cov_all(X, rinv.astype(np.float64))
     assert orc.rel_err(V[True], V[False]) < 3e-7
     assert orc.rel_err(V[True], ref) < 3e-6 and orc.rel_err(V[False], ref) < 3e-6
+
+
+@pytest.mark.parametrize("shape", [(400, 6, 16, 16), (333, 5, 16, 9), (180, 3, 15, 15), (70, 2, 16, 12)])
+def test_sources_on_the_fp64_matrix_cores_against_the_vector_alu_kernel(oa, shape):
+    """`precise`, 16 channels (15: padded copy of X), 9..16 sources: the same GEMM per bin on the fp64 matrix cores
+    (cov_hmfma64_kernel) against the float64 vector-ALU kernel it replaces there and against the oracle: float64 sums of exact
+    float64 products in both, different orders"""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F, M, seed=33)
+    rinv = np.random.default_rng(6).gamma(2.0, 1.0, (T, K)).astype(np.float32)
+    V = {}
+    for on in (True, False):
+        with oa.Plan(T, F, M, K, "laplace") as p:
+            p.set_precision("precise")
+            p.set_cov_hmfma(on)
+            p.set_x(X)
+            p.covariance()
+            p.t_set_rinv(rinv)
+            p.t_run_weighted_cov()
+            V[on] = p.t_get_v(np.complex128)
+    w = 1.0 / (np.float32(1) / rinv).astype(np.float64)
+    ref = orc.weighted_cov_all(X, w)
+    assert orc.rel_err(V[True], V[False]) < 1e-13
+    assert orc.rel_err(V[True], ref) < 1e-12 and orc.rel_err(V[False], ref) < 1e-12
+    assert np.array_equal(V[True], np.conj(np.swapaxes(V[True], -1, -2)))
