@@ -165,6 +165,11 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
                 // instructions per pair of matrix instructions -- on this chip the fp32 matrix instruction runs on the same
                 // ALUs as the vector instructions (measured: their times ADD), so every vector instruction here counts.
                 //   re = fma(row.y, xi_m, row.x * xr_m)          im = fma(row.y, xr_m, -(row.x * xi_m))
+                // (Order: the two chains interleaved -- mul re, fmac re, mul im, fmac im measured 4-7 % slower on the whole kernel --
+                //  and `re`, which the first matrix instruction reads, complete one vector instruction before the block ends: a
+                //  matrix instruction reading a register written by the LAST instruction of an asm block gets the OLD value, since
+                //  hipcc does not see the write and inserts no wait state; measured: two wait states (`s_nop 1`) suffice, a
+                //  64-lane vector instruction is four.)
                 float re, im;
                 asm("v_mul_f32_dpp %0, %2, %2 row_ror:%4 row_mask:0xf bank_mask:0xf\n\t"
                     "v_mul_f32_dpp %1, -%3, %2 row_ror:%4 row_mask:0xf bank_mask:0xf\n\t"
