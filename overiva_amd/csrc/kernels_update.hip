@@ -13,6 +13,8 @@
 // exchanged with sub-group shuffles; Gauss-Jordan elimination with partial pivoting never moves a
 // row (the pivot lane just broadcasts).  Every register array is indexed with compile-time
 // constants only (loops over columns are fully unrolled; run-time M and K enter as predicates).
+#include <cstdlib>
+
 #include "oiva_device.h"
 #include "update_chain.h"
 
@@ -424,6 +426,93 @@ __global__ __launch_bounds__(kBlock) void update_bg_kernel(UpdateArgs a) {
     if (fvalid && in) store_what<R>(a, ((size_t)f * M + j) * M + i, B.re, -B.im);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The determined case (K = M, AuxIVA): A w = e_s with A = W_hat^H V_s  <=>  w = V_s^-1 u,  u = column s of C = (W_hat^H)^-1.
+//   * V_s^-1: Hermitian positive definite, no pivot search, independent of W;
+//   * C: ONE pivoted elimination per bin and iteration; when source s replaces row s of W_hat^H by w'^H the inverse follows by
+//     the rank-one formula  C' = C - u (y - e_s^T) / y_s,  y = w'^H C  (Sherman-Morrison; y_s = sqrt(w^H V w) > 0);
+//   * w^H V_s w = u^H V_s^-1 u = u^H w: the normalisation (overiva.py:185-186) costs a dot product.
+// Per source two matrix-vector products, a dot product and a rank-one update instead of an M x M elimination with pivoting
+// (2049 x 235, float64, update stage: 8 / 8 55.5 -> 37.5 us, 7 / 7 47.8 -> 31.1, 6 / 6 40.6 -> 25.2, 5 / 5 33.8 -> 19.9, 4 / 4 10.5 -> 8.9,
+// 3 / 3 8.7 -> 6.9).  Same lane layout as update_sq_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int MP, typename R, int MT>
+__global__ __launch_bounds__(kBlock) void update_det_kernel(UpdateArgs a) {
+    constexpr int G = MP * MP;
+    const int tid = threadIdx.x;
+    const Sq<MP, R> sq(tid % G);
+    const int i = sq.i, j = sq.j;
+    const int f_raw = blockIdx.x * (kBlock / G) + tid / G;
+    const bool fvalid = f_raw < a.F;
+    const int f = fvalid ? f_raw : a.F - 1;
+    const int M = MT ? MT : a.M;
+    const int NA = M * M;
+    const bool in = i < M && j < M;
+    const Cx<R> eye = {R(i == j ? 1 : 0), R(0)};
+
+    Cx<R> B = eye;                        // B[i][j] = (W_hat^H)[i][j] = conj(W_hat[j][i]); identity outside M x M
+    if (in) {
+        R vr, vi;
+        load_what<R>(a, ((size_t)f * M + j) * M + i, vr, vi);
+        B = {vr, -vi};
+    }
+    if (a.wscale != nullptr && i < M) {  // overiva.py:163 / :167
+        const R sc = R(1) / R(a.wscale[i]);
+        B.re *= sc;
+        B.im *= sc;
+    }
+    int off = 0;
+    float sgn = 0.f;
+    if (in) herm_offsets(M, i, j, off, sgn);
+    const R invT = R(1) / R(a.T);
+    auto load_v = [&](int s) {
+        Cx<R> V = eye;
+        if (in) {
+            double sr, si;
+            sum_vpart(a.Vpart, a.vpart_f64, ((size_t)f * M + s) * NA + off, (size_t)a.F * M * NA, a.nsplit, sgn != 0.f, sr, si);
+            V = {R(sr) * invT, R(si) * R(sgn) * invT};
+        }
+        return V;
+    };
+    // (all M inverses V_s^-1 first, their eliminations interleaved step by step, measured no faster -- 8 / 8 float64 40.8 against
+    //  38.9 us, float32 33.6 against 29.8 -- the kernel is bound by the instructions it issues, two waves per SIMD, not by the
+    //  latency of one chain)
+    Cx<R> Vnext = load_v(0);
+    Cx<R> C = sq.inverse_pivoted(B, M);
+    static_for<MP>([&](auto sc_) {
+        constexpr int s = decltype(sc_)::value;
+        if (s < M) {
+            const Cx<R> V = Vnext;
+            if (s + 1 < M) Vnext = load_v(s + 1);
+            const Cx<R> Vinv = sq.herm_inverse(V, M);
+            const Cx<R> ui = sq.template rowb_c<s>(C);                 // u_i = C[i][s]
+            const Cx<R> uj = sq.at(C, j, s);                           // u_j
+            const Cx<R> wi = sq.rowsum(cmul(Vinv, uj));                // w = V^-1 u (not yet normalised), one entry per row
+            // y = w^H C, one entry per column;  y_s = w^H u = w^H V w =: d  (overiva.py:185; real)
+            const Cx<R> t = cmul(Cx<R>{wi.re, -wi.im}, C);
+            Cx<R> y = {sq.colsum(t.re), sq.colsum(t.im)};
+            const R d = sq.template rowb_c<s>(y.re);
+            const R sc = fast_rsqrt(d), rd = fast_rcp(d);
+            // with w' = w / sqrt(d):  C' = C - u (w'^H C - e_s^T) / (w'^H u) = C - (u / d) (y - sqrt(d) e_s^T)
+            const Cx<R> g = {ui.re * rd, ui.im * rd};
+            if (j == s) y.re -= d * sc;
+            cfms(C, g, y);
+            // (off the chain) row s of W_hat^H = w'^H
+            const Cx<R> wj = sq.transp(wi);
+            if (i == s && j < M) B = {wj.re * sc, -wj.im * sc};
+        }
+    });
+    if (fvalid && in) store_what<R>(a, ((size_t)f * M + j) * M + i, B.re, -B.im);
+}
+
+template <int MP, int MT>
+hipError_t launch_det_one(hipStream_t s, const UpdateArgs& a) {
+    const int bins_per_block = kBlock / (MP * MP);
+    dim3 grid((a.F + bins_per_block - 1) / bins_per_block);
+    hipLaunchKernelGGL((update_det_kernel<MP, double, MT>), grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int MP, int MT, int KT>
 hipError_t launch_sq_one(hipStream_t s, const UpdateArgs& a) {
     const int bins_per_block = kBlock / (MP * MP);
@@ -465,7 +554,13 @@ hipError_t launch_sq_m(hipStream_t s, const UpdateArgs& a) {
             if constexpr (MT > 3) if (a.K == 3) return launch_bg_one<MP, MT, 3>(s, a);
         }
     }
-    if (a.K == MT) return launch_sq_one<MP, MT, MT>(s, a);
+    if (a.K == MT) {
+        static const bool det = [] { const char* v = getenv("OIVA_UPDATE_DET"); return !(v && v[0] == '0'); }();
+        // (float64 only: in float32 the explicit inverses cost accuracy -- 8 / 8 mixture, 20 iterations: 6.5 reference floors
+        //  against 2.8 with the elimination per source -- and `fast` keeps the latter)
+        if (det && a.use_double && !a.init_only && MT >= 2) return launch_det_one<MP, MT>(s, a);
+        return launch_sq_one<MP, MT, MT>(s, a);
+    }
     if constexpr (MT > 1) if (a.K == 1) return launch_sq_one<MP, MT, 1>(s, a);
     if constexpr (MT > 2) if (a.K == 2) return launch_sq_one<MP, MT, 2>(s, a);
     if constexpr (MT > 3) if (a.K == 3) return launch_sq_one<MP, MT, 3>(s, a);

@@ -223,6 +223,40 @@ struct Sq {
         });
         return acc;
     }
+    // Inverse of a general matrix (identity outside M x M) by Gauss-Jordan elimination with partial pivoting on [A | I]: rows
+    // never move (the pivot row broadcasts), so row c of the inverse is the row that pivoted column c, divided by its pivot.
+    __device__ __forceinline__ Cx<R> inverse_pivoted(Cx<R> A, int M) const {
+        Cx<R> Rm = {R(i == j ? 1 : 0), R(0)};
+        Cx<R> piv = {R(1), R(0)};
+        bool used = false;
+        int src = i;
+        static_for<MP>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if (c < M) {
+                const Cx<R> aic = rowb_c<c>(A);
+                float mag = used ? 0.f : (float)(aic.re * aic.re + aic.im * aic.im);
+                unsigned key = (__float_as_uint(mag) & ~(unsigned)(MP - 1)) | (unsigned)(MP - 1 - i);
+                key = used ? 0u : key;
+                key = colmax(key);
+                const int p = MP - 1 - (int)(key & (unsigned)(MP - 1));
+                if (i == c) src = p;
+                const bool isp = (i == p);
+                const Cx<R> apc = colb(aic, p);
+                const Cx<R> apj = colb(A, p);
+                const Cx<R> rpj = colb(Rm, p);
+                const Cx<R> fct = cmul(aic, cinv(apc));
+                if (isp) {
+                    used = true;
+                    piv = apc;
+                } else {
+                    cfms(A, fct, apj);
+                    cfms(Rm, fct, rpj);
+                    if (j == c) A = {R(0), R(0)};
+                }
+            }
+        });
+        return colb(cmul(Rm, cinv(piv)), src);
+    }
     // Gauss-Jordan with partial pivoting over columns 0..npiv-1.  rhs is a per-row scalar replicated
     // along the row.  Returns, per lane: perm[c] = row that pivoted column c, piv = pivot element of
     // the lane's own row.
