@@ -5,6 +5,7 @@
 // bin and four matrix elements per lane (a 16 x 16 matrix has 256).
 #include "oiva_device.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace oiva {
@@ -369,12 +370,297 @@ __global__ __launch_bounds__(64) void update_wave16_kernel(UpdateArgs a) {
         if (in[e]) store_what<R>(a, ((size_t)f * M + 4 * e + q) * M + i, B[e].re, -B[e].im);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The determined case (K = M, AuxIVA; BASELINE configs[4] is 16 x 16), float64: A w = e_s with A = W_hat^H V_s as
+//   w = V_s^-1 u,  u = column s of C = (W_hat^H)^-1
+// (the scheme of update_det_kernel, kernels_update.hip, in this kernel's lane layout): C from ONE pivoted elimination on
+// [W_hat^H | I] per bin and iteration, updated after every source by the rank-one formula
+//   C' = C - (u / d) (y - sqrt(d) e_s^T),   y = w^H C,   d = y_s = w^H u = w^H V_s w   (overiva.py:185)
+// and V_s^-1 by an elimination without pivot search (Hermitian positive definite) and without the product W_hat^H V_s.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename VT>
+__global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
+    using R = double;
+    __shared__ LdsDet<R> s;
+    const int lane = threadIdx.x, i = lane >> 2, q = lane & 3;
+    const int f = blockIdx.x, M = a.M, NA = M * M;
+    C2<R> B[4];
+    int off[4];
+    float sgn[4];
+    bool in[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * e + q;
+        in[e] = i < M && c < M;
+        B[e] = {R(i == c ? 1 : 0), R(0)};
+        off[e] = 0;
+        sgn[e] = 0.f;
+        if (in[e]) {
+            R vr, vi;
+            load_what<R>(a, ((size_t)f * M + c) * M + i, vr, vi);
+            B[e] = {vr, -vi};
+            herm_off(M, i, c, off[e], sgn[e]);
+        }
+    }
+    if (a.wscale != nullptr && i < M) {                   // overiva.py:163 / :167
+        const R sc = R(1) / R(a.wscale[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) B[e] = {B[e].re * sc, B[e].im * sc};
+    }
+    // the partials of source s + 1 are in flight while source s is worked on (as update_wave16_kernel)
+    constexpr int kAhead = 8;
+    const VT* vbase = static_cast<const VT*>(a.Vpart);
+    const size_t vstride = (size_t)a.F * M * NA;
+    const int nahead = a.nsplit < kAhead ? a.nsplit : kAhead;
+    auto fetch = [&](int src, int sp, VT (&raw)[4]) {
+        const VT* p = vbase + (size_t)sp * vstride + ((size_t)f * M + src) * NA + lane * 4;
+        if ((M & 1) == 0) {
+            if (lane * 4 < NA) {
+                if constexpr (sizeof(VT) == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(p);
+                    raw[0] = v.x, raw[1] = v.y, raw[2] = v.z, raw[3] = v.w;
+                } else {
+                    const double2 v0 = reinterpret_cast<const double2*>(p)[0], v1 = reinterpret_cast<const double2*>(p)[1];
+                    raw[0] = v0.x, raw[1] = v0.y, raw[2] = v1.x, raw[3] = v1.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (lane * 4 + r < NA) raw[r] = p[r];
+        }
+    };
+    VT raw[kAhead][4] = {};
+    auto fetch_ahead = [&](int src) {
+#pragma unroll
+        for (int sp = 0; sp < kAhead; ++sp)
+            if (sp < nahead) fetch(src, sp, raw[sp]);
+    };
+    fetch_ahead(0);
+
+    // ---- C = (W_hat^H)^-1: Gauss-Jordan with partial pivoting on [A | Rm], rows never move; row c of the inverse is the row
+    //      that pivoted column c, divided by its pivot
+    C2<R> C[4];
+    {
+        C2<R> A[4], Rm[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            A[e] = B[e];
+            Rm[e] = {R(i == 4 * e + q ? 1 : 0), R(0)};
+        }
+        bool used = false;
+        C2<R> piv = {R(1), R(0)};
+        int mycol = i;
+        auto step = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int ce = c >> 2, cq = c & 3;
+            constexpr int e0 = (c + 1) >> 2;               // elements of A below e0 hold only eliminated columns
+            const C2<R> aic = quad_bcast<cq>(A[ce]);
+            const float mag = (float)(aic.re * aic.re + aic.im * aic.im);
+            unsigned key = used ? 0u : ((__float_as_uint(mag) & ~31u) | 16u | (unsigned)(15 - i));
+            unsigned o;
+            o = dpp<kDppRor4>(key); key = o > key ? o : key;
+            o = dpp<kDppRor8>(key); key = o > key ? o : key;
+            key = swapmax32(swapmax16(key));
+            const int p = 15 - (int)(__builtin_amdgcn_readfirstlane((int)key) & 15);
+            wave_lds_sync();
+            if (i == p) {
+#pragma unroll
+                for (int e = e0; e < 4; ++e) s.prow[q][e] = A[e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s.V[0][q * 4 + e] = Rm[e];
+                if (q == 0) s.ppiv = aic;
+            }
+            wave_lds_sync();
+            const C2<R> apc = s.ppiv;
+            const bool mine = i == p;
+            used = used || mine;
+            mycol = mine ? c : mycol;
+            piv.re = mine ? apc.re : piv.re;
+            piv.im = mine ? apc.im : piv.im;
+            C2<R> fct = cmul(aic, cinv_fast(apc));
+            fct.re = mine ? R(0) : fct.re;
+            fct.im = mine ? R(0) : fct.im;
+#pragma unroll
+            for (int e = e0; e < 4; ++e) {
+                const C2<R> r = s.prow[q][e];
+                A[e].re -= fct.re * r.re - fct.im * r.im;
+                A[e].im -= fct.re * r.im + fct.im * r.re;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const C2<R> r = s.V[0][q * 4 + e];
+                Rm[e].re -= fct.re * r.re - fct.im * r.im;
+                Rm[e].im -= fct.re * r.im + fct.im * r.re;
+            }
+        };
+#define OIVA_D16_STEP(c) \
+    if (c < M) step(std::integral_constant<int, c>{});
+        OIVA_D16_STEP(0) OIVA_D16_STEP(1) OIVA_D16_STEP(2) OIVA_D16_STEP(3) OIVA_D16_STEP(4) OIVA_D16_STEP(5) OIVA_D16_STEP(6)
+        OIVA_D16_STEP(7) OIVA_D16_STEP(8) OIVA_D16_STEP(9) OIVA_D16_STEP(10) OIVA_D16_STEP(11) OIVA_D16_STEP(12)
+        OIVA_D16_STEP(13) OIVA_D16_STEP(14) OIVA_D16_STEP(15)
+#undef OIVA_D16_STEP
+        wave_lds_sync();
+        {
+            const C2<R> ip = cinv(piv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s.V[mycol][q * 4 + e] = cmul(Rm[e], ip);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) C[e] = s.V[i][q * 4 + e];
+        wave_lds_sync();
+    }
+
+    // ---- in-place inverse of a Hermitian positive definite matrix (identity outside M x M): no pivot search
+    auto herm_inverse = [&](C2<R> (&A)[4]) {
+        auto step = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int ke = k >> 2, kq = k & 3;
+            const C2<R> aik = quad_bcast<kq>(A[ke]);       // A[i][k]
+            wave_lds_sync();
+            if (i == k) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s.prow[q][e] = A[e];
+                if (q == 0) s.ppiv = aik;                    // A[k][k]
+            }
+            wave_lds_sync();
+            // (the pivots of a Hermitian positive definite elimination are real: Schur complements stay Hermitian)
+            const R pr = s.ppiv.re;
+            R d = __builtin_amdgcn_rcp(pr);
+            d = fma(fma(-pr, d, 1.0), d, d);
+            d = fma(fma(-pr, d, 1.0), d, d);
+            const C2<R> ad = {aik.re * d, aik.im * d};
+            const bool rowk = i == k;
+            // every row: A[i][c] -= f A[k][c] with f = A[i][k] d -- and f = 1 - d on row k itself, which leaves A[k][c] d there;
+            // column k (where that gives 0 and 1) is then set to -A[i][k] d, and to d on the diagonal
+            const C2<R> fct = {rowk ? R(1) - d : ad.re, rowk ? R(0) : ad.im};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const C2<R> r = s.prow[q][e];
+                A[e].re -= fct.re * r.re - fct.im * r.im;
+                A[e].im -= fct.re * r.im + fct.im * r.re;
+            }
+            if (q == kq) {
+                A[ke].re = rowk ? d : -ad.re;
+                A[ke].im = rowk ? R(0) : -ad.im;
+            }
+        };
+#define OIVA_H16_STEP(c) \
+    if (c < M) step(std::integral_constant<int, c>{});
+        OIVA_H16_STEP(0) OIVA_H16_STEP(1) OIVA_H16_STEP(2) OIVA_H16_STEP(3) OIVA_H16_STEP(4) OIVA_H16_STEP(5) OIVA_H16_STEP(6)
+        OIVA_H16_STEP(7) OIVA_H16_STEP(8) OIVA_H16_STEP(9) OIVA_H16_STEP(10) OIVA_H16_STEP(11) OIVA_H16_STEP(12)
+        OIVA_H16_STEP(13) OIVA_H16_STEP(14) OIVA_H16_STEP(15)
+#undef OIVA_H16_STEP
+    };
+
+    const R invT = R(1) / R(a.T);
+    for (int src = 0; src < M; ++src) {
+        double acc[4] = {0., 0., 0., 0.};
+#pragma unroll
+        for (int sp = 0; sp < kAhead; ++sp)
+            if (sp < nahead) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] += (double)raw[sp][r];
+            }
+        for (int sp = kAhead; sp < a.nsplit; ++sp) {           // very long frame axes only
+            VT more[4] = {VT(0), VT(0), VT(0), VT(0)};
+            fetch(src, sp, more);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += (double)more[r];
+        }
+        if (src + 1 < M) fetch_ahead(src + 1);
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s.pk[lane * 4 + r] = R(acc[r]);
+        wave_lds_sync();
+        C2<R> Vi[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Vi[e] = {R(i == 4 * e + q ? 1 : 0), R(0)};
+            if (in[e]) {
+                Vi[e] = {s.pk[off[e]] * invT, R(0)};
+                if (sgn[e] != 0.f) Vi[e].im = s.pk[off[e] + 1] * R(sgn[e]) * invT;
+            }
+        }
+        herm_inverse(Vi);
+        // u = column src of C: u_i for the row, u_c for the lane's four columns (through LDS)
+        const int se = src >> 2, sq = src & 3;
+        wave_lds_sync();
+        if (q == sq) {
+            C2<R> v = C[0];
+            v.re = se == 1 ? C[1].re : (se == 2 ? C[2].re : (se == 3 ? C[3].re : v.re));
+            v.im = se == 1 ? C[1].im : (se == 2 ? C[2].im : (se == 3 ? C[3].im : v.im));
+            s.w[i] = v;
+        }
+        wave_lds_sync();
+        const C2<R> ui = s.w[i];
+        // w = V^-1 u (not yet normalised): row i from this lane's four columns, then over the quad
+        R wr = R(0), wim = R(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const C2<R> uc = s.w[4 * e + q];
+            wr += Vi[e].re * uc.re - Vi[e].im * uc.im;
+            wim += Vi[e].re * uc.im + Vi[e].im * uc.re;
+        }
+        const C2<R> wi = {quad_sum(wr), quad_sum(wim)};
+        // y = w^H C: column sums over the 16 rows (lanes of equal q)
+        C2<R> y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const C2<R> x = cmul(cconj(wi), C[e]);
+            y[e] = {wave_sum16(x.re), wave_sum16(x.im)};
+        }
+        // d = y_src (real): held by the lanes q == sq in element se
+        wave_lds_sync();
+        if (lane == sq) {
+            const R v = se == 0 ? y[0].re : (se == 1 ? y[1].re : (se == 2 ? y[2].re : y[3].re));
+            s.ppiv = {v, R(0)};
+        }
+        if (q == 0) s.w[i] = wi;
+        wave_lds_sync();
+        const R d = s.ppiv.re;
+        double rd = __builtin_amdgcn_rcp(d);
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        const R sc = R(1) / sqrt(d);
+        const C2<R> g = {ui.re * rd, ui.im * rd};
+        const R sqd = d * sc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            C2<R> ye = y[e];
+            if (4 * e + q == src) ye.re -= sqd;
+            C[e].re -= g.re * ye.re - g.im * ye.im;
+            C[e].im -= g.re * ye.im + g.im * ye.re;
+        }
+        // row src of W_hat^H = (w / sqrt(d))^H
+        if (i == src) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const C2<R> wc = s.w[4 * e + q];
+                B[e] = {wc.re * sc, -wc.im * sc};
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (in[e]) store_what<R>(a, ((size_t)f * M + 4 * e + q) * M + i, B[e].re, -B[e].im);
+}
+
 }  // namespace
 
 hipError_t launch_update_wave16(hipStream_t s, const UpdateArgs& a) {
     dim3 grid(a.F);
     auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(64), 0, s, a); };
     const bool over = a.K < a.M;
+    static const bool det = [] { const char* v = getenv("OIVA_UPDATE_DET"); return !(v && v[0] == '0'); }();
+    if (det && !over && a.use_double && !a.init_only) {
+        if (a.vpart_f64)
+            go(update_det16_kernel<double>);
+        else
+            go(update_det16_kernel<float>);
+        return hipGetLastError();
+    }
 #define OIVA_GO(RR, VV)                                         \
     if (over) go(update_wave16_kernel<RR, VV, true>);           \
     else go(update_wave16_kernel<RR, VV, false>);

@@ -187,12 +187,13 @@ struct Sq {
             if (k < M) {
                 const Cx<R> rk = colb(A, k);                 // A[k][j]
                 const Cx<R> ck = rowb_c<k>(A);               // A[i][k]
-                const Cx<R> d = cinv(at_c<k, k>(A));         // 1 / A[k][k]
-                const Cx<R> rkd = cmul(rk, d);
+                const R d = fast_rcp(at_c<k, k>(A).re);      // 1 / A[k][k]: the pivots of this elimination are real (Schur
+                                                             // complements of a Hermitian matrix stay Hermitian)
+                const Cx<R> rkd = {rk.re * d, rk.im * d};
                 if (i == k)
-                    A = (j == k) ? d : rkd;
+                    A = (j == k) ? Cx<R>{d, R(0)} : rkd;
                 else if (j == k)
-                    A = Cx<R>{-(ck.re * d.re - ck.im * d.im), -(ck.re * d.im + ck.im * d.re)};
+                    A = Cx<R>{-(ck.re * d), -(ck.im * d)};
                 else
                     cfms(A, ck, rkd);
             }
