@@ -362,11 +362,11 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Structured form of the same update for 1 .. 3 sources with background channels (K < M; the chain itself also takes 4): the chain that
+// Structured form of the same update for 1 or 2 sources with background channels (K < M): the chain that
 // depends on W is a K x K solve and a few matrix-vector products instead of an M x M elimination with pivoting.
 //   W_hat^H = [[W^H], [J^H | -I]],  A = W_hat^H V,  A w = e_s   <=>   W_hat^H u = e_s,  u = V w:
 //     rows >= K :  u_bot = J^H u_top
-//     rows <  K :  Q u_top = e_s   with   Q = B_tt + B_tb B_bt   (B = W_hat^H in K | M-K blocks)      K x K, by cofactors
+//     rows <  K :  Q u_top = e_s   with   Q = B_tt + B_tb B_bt   (B = W_hat^H in K | M-K blocks)      K x K
 //     w = V^-1 u                   V^-1 of the Hermitian positive definite V_s needs no pivoting and does not
 //                                  depend on W: all K inverses are formed before the chain starts
 //   w /= sqrt(w^H V w)  (overiva.py:185-186);  J from (W^H Cx)[:, :K]^-1 (W^H Cx)[:, K:] in closed form (:96-98).
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <int MP, typename R, int MT, int KT>
 __global__ __launch_bounds__(kBlock) void update_bg_kernel(UpdateArgs a) {
-    static_assert(KT >= 1 && KT <= 4, "closed-form K x K solves");
+    static_assert(KT == 1 || KT == 2, "closed-form K x K solves");
     constexpr int G = MP * MP;
     constexpr int K = KT;
     const int tid = threadIdx.x;
@@ -505,6 +505,127 @@ __global__ __launch_bounds__(kBlock) void update_det_kernel(UpdateArgs a) {
     if (fvalid && in) store_what<R>(a, ((size_t)f * M + j) * M + i, B.re, -B.im);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sources with background channels (K < M), any K: the column the IP1 solve needs has a closed form that never touches J.
+// With W_hat^H = [[W^H], [J^H | -I]] and J from the orthogonality constraint (overiva.py:96-98, J = (W^H Cx)[:, :K]^-1
+// (W^H Cx)[:, K:]):
+//     column s of (W_hat^H)^-1  =  P G^-1 e_s,     P = Cx W  (M x K),   G = W^H Cx W = W^H P  (K x K, Hermitian positive definite)
+// (block inverse: the first K columns are [Q^-1; J^H Q^-1] with Q = W^H [I; J^H] = G (W^H Cx)[:, :K]^-H), so per source
+//     c = P G^-1 e_s,   w = V_s^-1 c,   w /= sqrt(c^H w)   (c^H w = w^H V_s w, overiva.py:185),   column s of P and row / column s of G
+// follow w -- two eliminations WITHOUT pivot search (M x M and K x K), three matrix-vector products, one product with w^H --
+// and J is formed ONCE, after the last source, from the final W (the reference forms it after every source, :189-190, but uses
+// only the last).  Float64.  Same lane layout as update_sq_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int MP, int MT, int KT>
+__global__ __launch_bounds__(kBlock) void update_gram_kernel(UpdateArgs a) {
+    using R = double;
+    constexpr int G_ = MP * MP;
+    const int tid = threadIdx.x;
+    const Sq<MP, R> sq(tid % G_);
+    const int i = sq.i, j = sq.j;
+    const int f_raw = blockIdx.x * (kBlock / G_) + tid / G_;
+    const bool fvalid = f_raw < a.F;
+    const int f = fvalid ? f_raw : a.F - 1;
+    const int M = MT ? MT : a.M, K = KT ? KT : a.K;
+    const int NA = M * M;
+    const bool in = i < M && j < M;
+    const Cx<R> zero = {R(0), R(0)};
+    const Cx<R> eye = {R(i == j ? 1 : 0), R(0)};
+
+    Cx<R> B = eye;                        // B[i][j] = (W_hat^H)[i][j] = conj(W_hat[j][i]); identity outside M x M
+    if (in) {
+        R vr, vi;
+        load_what<R>(a, ((size_t)f * M + j) * M + i, vr, vi);
+        B = {vr, -vi};
+    }
+    if (a.wscale != nullptr && i < K) {  // overiva.py:163 / :167
+        const R sc = R(1) / R(a.wscale[i]);
+        B.re *= sc;
+        B.im *= sc;
+    }
+    int off = 0;
+    float sgn = 0.f;
+    if (in) herm_offsets(M, i, j, off, sgn);
+    Cx<R> C = zero;                       // Cx
+    if (in) {
+        const double* p = a.Cx + (size_t)f * NA + off;
+        C.re = R(p[0]);
+        if (sgn != 0.f) C.im = R(sgn * p[1]);
+    }
+    const R invT = R(1) / R(a.T);
+    auto load_v = [&](int s) {
+        Cx<R> V = eye;
+        if (in) {
+            double sr, si;
+            sum_vpart(a.Vpart, a.vpart_f64, ((size_t)f * K + s) * NA + off, (size_t)a.F * K * NA, a.nsplit, sgn != 0.f, sr, si);
+            V = {R(sr) * invT, R(si) * R(sgn) * invT};
+        }
+        return V;
+    };
+    Cx<R> Vnext = load_v(0);
+    // Tm = W^H Cx on rows < K (Tm[k][j]);  P = Tm^H (P[i][k] on columns < K);  G = W^H P on (k, l) < K, identity outside
+    Cx<R> Tm = sq.matmul(B, C, M);
+    if (i >= K) Tm = zero;
+    Cx<R> P = sq.transp(Tm);
+    P = {P.re, -P.im};
+    // G[k][l] = sum_i conj(W[i][k]) P[i][l] = sum_m B[k][m] P[m][l]
+    Cx<R> Gm = sq.matmul(B, P, M);
+    if (i >= K || j >= K) Gm = eye;
+    static_for<MP>([&](auto sc_) {
+        constexpr int s = decltype(sc_)::value;
+        if (s < K) {
+            const Cx<R> V = Vnext;
+            if (s + 1 < K) Vnext = load_v(s + 1);
+            const Cx<R> Vinv = sq.herm_inverse(V, M);
+            const Cx<R> Ginv = sq.herm_inverse(Gm, K);
+            const Cx<R> gj = sq.at(Ginv, j, s);                        // g_j = (G^-1)[j][s]   (0 for j >= K: identity there)
+            const Cx<R> ci = sq.rowsum(cmul(P, j < K ? gj : zero));    // c = P g, one entry per row
+            const Cx<R> cj = sq.transp(ci);
+            Cx<R> wi = sq.rowsum(cmul(Vinv, j < M ? cj : zero));       // w = V^-1 c
+            const R d = sq.allsum(j == 0 && i < M ? wi.re * ci.re + wi.im * ci.im : R(0));     // c^H w = w^H V w
+            const R sc = fast_rsqrt(d);
+            wi = {i < M ? wi.re * sc : R(0), i < M ? wi.im * sc : R(0)};
+            const Cx<R> wj = sq.transp(wi);
+            if (i == s && j < M) B = {wj.re, -wj.im};
+            // column s of P = Cx w;  row s of G = w^H P, column s its conjugate
+            const Cx<R> pi = sq.rowsum(cmul(C, wj));
+            if (j == s) P = pi;
+            const Cx<R> t = cmul(Cx<R>{wi.re, -wi.im}, P);
+            const Cx<R> y = {sq.colsum(t.re), sq.colsum(t.im)};        // y_l = w^H P[:, l]
+            const Cx<R> yt = sq.transp(y);                             // lane (k, s): y_k
+            if (i == s && j < K) Gm = (j == s) ? Cx<R>{y.re, R(0)} : y;
+            if (j == s && i < K && i != s) Gm = {yt.re, -yt.im};
+        }
+    });
+    // J = (W^H Cx)[:, :K]^-1 (W^H Cx)[:, K:] from the final W (overiva.py:189-190 -> :96-98): Tm = P^H on rows < K
+    {
+        const Cx<R> Pt = sq.transp(P);
+        Cx<R> Gj = (i < K) ? Cx<R>{Pt.re, -Pt.im} : eye;
+        Cx<R> dummy = zero;
+        int perm[MP];
+        Cx<R> piv = {R(1), R(0)};
+        sq.gauss_jordan(Gj, dummy, K, i >= K, perm, piv);
+        const Cx<R> Jn = cmul(Gj, cinv(piv));  // on row perm[m]: J[m][j-K] for j >= K
+#pragma unroll
+        for (int m = 0; m < MP; ++m) {
+            if (m < K) {
+                const Cx<R> row = sq.colb(Jn, perm[m]);   // lane (i, j): J[m][j-K]
+                const Cx<R> tr = sq.transp(row);          // lane (i, j): J[m][i-K]
+                if (j == m && i >= K && i < M) B = {tr.re, -tr.im};
+            }
+        }
+    }
+    if (fvalid && in) store_what<R>(a, ((size_t)f * M + j) * M + i, B.re, -B.im);
+}
+
+template <int MP, int MT, int KT>
+hipError_t launch_gram_one(hipStream_t s, const UpdateArgs& a) {
+    const int bins_per_block = kBlock / (MP * MP);
+    dim3 grid((a.F + bins_per_block - 1) / bins_per_block);
+    hipLaunchKernelGGL((update_gram_kernel<MP, MT, KT>), grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int MP, int MT>
 hipError_t launch_det_one(hipStream_t s, const UpdateArgs& a) {
     const int bins_per_block = kBlock / (MP * MP);
@@ -541,17 +662,25 @@ hipError_t launch_bg_one(hipStream_t s, const UpdateArgs& a) {
 // sweeps use (overiva_sim_config.json: 2..8 microphones, 1..4 targets, determined AuxIVA): 1, 2, 3, 4, MT
 template <int MP, int MT>
 hipError_t launch_sq_m(hipStream_t s, const UpdateArgs& a) {
-    // 1 .. 3 sources with background channels: the structured chain (the J initialisation of the prologue keeps
-    // the generic kernel)
+    // 1 or 2 sources with background channels: the structured chain with closed-form K x K solves; 3 and more (float64): the
+    // Gram form (update_gram_kernel).  2049 x 235, float64, update stage, generic kernel -> this dispatch: 8 / 3 23.0 -> 21.9 us,
+    // 6 / 3 20.2 -> 16.6, 5 / 3 18.7 -> 15.4, 8 / 4 39.5 -> 28.4, 6 / 4 37.8 -> 22.2, 8 / 6 64.2 -> 37.3; with one or two sources the
+    // Gram form is on a par with the structured chain (8 / 2 15.4 against 13.7 us, 6 / 2 11.2 / 11.9, 8 / 1 8.6 / 7.7), which
+    // the X-resident kernel shares.  (The J initialisation of the prologue keeps the generic kernel.)
     if constexpr (MP >= 4) {
         if (!a.init_only && a.K < MT) {
+            static const int gram = [] { const char* v = getenv("OIVA_UPDATE_GRAM"); return v ? atoi(v) : 1; }();
+            if (gram == 2 && a.use_double) {      // (measurement only: every K through the Gram form)
+                if (a.K == 1) return launch_gram_one<MP, MT, 1>(s, a);
+                if (a.K == 2) return launch_gram_one<MP, MT, 2>(s, a);
+            }
             if (a.K == 2) return launch_bg_one<MP, MT, 2>(s, a);
             if (a.K == 1) return launch_bg_one<MP, MT, 1>(s, a);
-            // (three sources: the 3 x 3 solves by cofactors, every lane computing all of them -- 2049 x 235, float64: 8 / 3 29.4 ->
-            //  25.8 us, 7 / 3 28.1 -> 22.6.  Four sources the same way measured SLOWER than the pivoting elimination over the
-            //  lanes -- 8 / 4 39.2 -> 44.3 us, 6 / 4 37.8 -> 39.8: the redundant 4 x 4 cofactors cost what they save -- and keep
-            //  the generic kernel.)
-            if constexpr (MT > 3) if (a.K == 3) return launch_bg_one<MP, MT, 3>(s, a);
+            if (gram && a.use_double) {
+                if constexpr (MT > 3) if (a.K == 3) return launch_gram_one<MP, MT, 3>(s, a);
+                if constexpr (MT > 4) if (a.K == 4) return launch_gram_one<MP, MT, 4>(s, a);
+                if constexpr (MT > 5) return launch_gram_one<MP, MT, 0>(s, a);
+            }
         }
     }
     if (a.K == MT) {

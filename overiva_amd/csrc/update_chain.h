@@ -295,73 +295,10 @@ struct Sq {
 
 
 // ---------------------------------------------------------------------------------------------
-// The update for 1 .. 4 sources with background channels (K < M), given V_s for every source: see the comment at
+// The update for 1 or 2 sources with background channels (K < M), given V_s for every source: see the comment at
 // update_bg_kernel (kernels_update.hip).  Lane (i, j) of the bin's MP x MP group holds element [i][j] of
 // B = W_hat^H (in/out), C = Cx, V[s] = V_s (identity outside M x M).
 // ---------------------------------------------------------------------------------------------
-// Adjugate and determinant of a 3 x 3 or 4 x 4 complex matrix held whole by the lane (inverse = adj / det): division-free
-// up to the one reciprocal of the determinant, no pivot search, every product independent of the others (4 x 4: through the
-// twelve 2 x 2 minors of the row pairs).
-template <int K, typename R>
-__device__ __forceinline__ void small_adj(const Cx<R> (&q)[K][K], Cx<R> (&adj)[K][K], Cx<R>& det) {
-    static_assert(K == 3 || K == 4, "");
-    auto d2 = [](const Cx<R>& a, const Cx<R>& b, const Cx<R>& c, const Cx<R>& d) {     // a b - c d
-        Cx<R> r = cmul(a, b);
-        cfms(r, c, d);
-        return r;
-    };
-    auto neg = [](const Cx<R>& a) { return Cx<R>{-a.re, -a.im}; };
-    if constexpr (K == 3) {
-        adj[0][0] = d2(q[1][1], q[2][2], q[1][2], q[2][1]);
-        adj[0][1] = d2(q[0][2], q[2][1], q[0][1], q[2][2]);
-        adj[0][2] = d2(q[0][1], q[1][2], q[0][2], q[1][1]);
-        adj[1][0] = d2(q[1][2], q[2][0], q[1][0], q[2][2]);
-        adj[1][1] = d2(q[0][0], q[2][2], q[0][2], q[2][0]);
-        adj[1][2] = d2(q[0][2], q[1][0], q[0][0], q[1][2]);
-        adj[2][0] = d2(q[1][0], q[2][1], q[1][1], q[2][0]);
-        adj[2][1] = d2(q[0][1], q[2][0], q[0][0], q[2][1]);
-        adj[2][2] = d2(q[0][0], q[1][1], q[0][1], q[1][0]);
-        det = cmul(q[0][0], adj[0][0]);
-        cfma(det, q[0][1], adj[1][0]);
-        cfma(det, q[0][2], adj[2][0]);
-    } else {
-        const Cx<R> s0 = d2(q[0][0], q[1][1], q[1][0], q[0][1]), s1 = d2(q[0][0], q[1][2], q[1][0], q[0][2]),
-                    s2 = d2(q[0][0], q[1][3], q[1][0], q[0][3]), s3 = d2(q[0][1], q[1][2], q[1][1], q[0][2]),
-                    s4 = d2(q[0][1], q[1][3], q[1][1], q[0][3]), s5 = d2(q[0][2], q[1][3], q[1][2], q[0][3]);
-        const Cx<R> c5 = d2(q[2][2], q[3][3], q[3][2], q[2][3]), c4 = d2(q[2][1], q[3][3], q[3][1], q[2][3]),
-                    c3 = d2(q[2][1], q[3][2], q[3][1], q[2][2]), c2 = d2(q[2][0], q[3][3], q[3][0], q[2][3]),
-                    c1 = d2(q[2][0], q[3][2], q[3][0], q[2][2]), c0 = d2(q[2][0], q[3][1], q[3][0], q[2][1]);
-        det = cmul(s0, c5);
-        cfms(det, s1, c4);
-        cfma(det, s2, c3);
-        cfma(det, s3, c2);
-        cfms(det, s4, c1);
-        cfma(det, s5, c0);
-        auto t3 = [](const Cx<R>& a, const Cx<R>& x, const Cx<R>& b, const Cx<R>& y, const Cx<R>& c, const Cx<R>& z) {   // a x - b y + c z
-            Cx<R> r = cmul(a, x);
-            cfms(r, b, y);
-            cfma(r, c, z);
-            return r;
-        };
-        adj[0][0] = t3(q[1][1], c5, q[1][2], c4, q[1][3], c3);
-        adj[0][1] = neg(t3(q[0][1], c5, q[0][2], c4, q[0][3], c3));
-        adj[0][2] = t3(q[3][1], s5, q[3][2], s4, q[3][3], s3);
-        adj[0][3] = neg(t3(q[2][1], s5, q[2][2], s4, q[2][3], s3));
-        adj[1][0] = neg(t3(q[1][0], c5, q[1][2], c2, q[1][3], c1));
-        adj[1][1] = t3(q[0][0], c5, q[0][2], c2, q[0][3], c1);
-        adj[1][2] = neg(t3(q[3][0], s5, q[3][2], s2, q[3][3], s1));
-        adj[1][3] = t3(q[2][0], s5, q[2][2], s2, q[2][3], s1);
-        adj[2][0] = t3(q[1][0], c4, q[1][1], c2, q[1][3], c0);
-        adj[2][1] = neg(t3(q[0][0], c4, q[0][1], c2, q[0][3], c0));
-        adj[2][2] = t3(q[3][0], s4, q[3][1], s2, q[3][3], s0);
-        adj[2][3] = neg(t3(q[2][0], s4, q[2][1], s2, q[2][3], s0));
-        adj[3][0] = neg(t3(q[1][0], c3, q[1][1], c1, q[1][2], c0));
-        adj[3][1] = t3(q[0][0], c3, q[0][1], c1, q[0][2], c0);
-        adj[3][2] = neg(t3(q[3][0], s3, q[3][1], s1, q[3][2], s0));
-        adj[3][3] = t3(q[2][0], s3, q[2][1], s1, q[2][2], s0);
-    }
-}
-
 // The part of the chain that needs W_hat^H and Cx only (not the covariances): T = W^H Cx on rows < K, and the transpose of B.
 template <int MP, typename R>
 __device__ __forceinline__ void bg_pre(const Sq<MP, R>& sq, const Cx<R>& B, const Cx<R>& C, int M, Cx<R>& Tm, Cx<R>& Bt) {
@@ -373,7 +310,7 @@ __device__ __forceinline__ void bg_pre(const Sq<MP, R>& sq, const Cx<R>& B, cons
 template <int MP, typename R, int K, int S>
 __device__ __forceinline__ void bg_source(const Sq<MP, R>& sq, Cx<R>& B, const Cx<R>& C, const Cx<R>& Vs, const Cx<R>& Vinvs, Cx<R>& Tm, Cx<R>& Bt,
                                           int M) {
-    static_assert(K >= 1 && K <= 4, "closed-form K x K solves");
+    static_assert(K == 1 || K == 2, "closed-form K x K solves");
     constexpr int s = S;
     const int i = sq.i, j = sq.j;
     const Cx<R> zero = {R(0), R(0)};
@@ -387,7 +324,7 @@ __device__ __forceinline__ void bg_source(const Sq<MP, R>& sq, Cx<R>& B, const C
     Cx<R> u0, u1 = zero;
     if constexpr (K == 1) {
         u0 = cinv(sq.template at_c<0, 0>(Q));
-    } else if constexpr (K == 2) {
+    } else {
         const Cx<R> q00 = sq.template at_c<0, 0>(Q), q01 = sq.template at_c<0, 1>(Q), q10 = sq.template at_c<1, 0>(Q),
                     q11 = sq.template at_c<1, 1>(Q);
         Cx<R> det = cmul(q00, q11);
@@ -396,28 +333,12 @@ __device__ __forceinline__ void bg_source(const Sq<MP, R>& sq, Cx<R>& B, const C
         u0 = s == 0 ? cmul(q11, idet) : cmul(Cx<R>{-q01.re, -q01.im}, idet);
         u1 = s == 0 ? cmul(Cx<R>{-q10.re, -q10.im}, idet) : cmul(q00, idet);
     }
-    Cx<R> u2 = zero, u3 = zero;
-    if constexpr (K >= 3) {
-        // the whole K x K matrix in every lane (one bin per wavefront: scalar broadcasts), column s of its inverse by cofactors
-        Cx<R> q[K][K], adj[K][K], det;
-        static_for<K>([&](auto ac) {
-            static_for<K>([&](auto bc) { q[decltype(ac)::value][decltype(bc)::value] = sq.template at_c<decltype(ac)::value, decltype(bc)::value>(Q); });
-        });
-        small_adj<K, R>(q, adj, det);
-        const Cx<R> idet = cinv(det);
-        u0 = cmul(adj[0][s], idet);
-        u1 = cmul(adj[1][s], idet);
-        u2 = cmul(adj[2][s], idet);
-        if constexpr (K == 4) u3 = cmul(adj[3][s], idet);
-    }
     // u, one entry per column: u_j = u_top[j] (j < K) | sum_m B[j][m] u_top[m] (K <= j < M)
     Cx<R> ub = cmul(sq.colb(Bt, 0), u0);
-    if constexpr (K >= 2) cfma(ub, sq.colb(Bt, 1), u1);
-    if constexpr (K >= 3) cfma(ub, sq.colb(Bt, 2), u2);
-    if constexpr (K >= 4) cfma(ub, sq.colb(Bt, 3), u3);
+    if constexpr (K == 2) cfma(ub, sq.colb(Bt, 1), u1);
     // (component-wise selects: a select of an (re, im) pair may be compiled into a two-slot stack array indexed by the lane)
-    const bool j0 = j == 0, j1 = K >= 2 && j == 1, j2 = K >= 3 && j == 2, j3 = K >= 4 && j == 3;
-    Cx<R> uj = {j0 ? u0.re : (j1 ? u1.re : (j2 ? u2.re : (j3 ? u3.re : ub.re))), j0 ? u0.im : (j1 ? u1.im : (j2 ? u2.im : (j3 ? u3.im : ub.im)))};
+    const bool j0 = j == 0, j1 = K == 2 && j == 1;
+    Cx<R> uj = {j0 ? u0.re : (j1 ? u1.re : ub.re), j0 ? u0.im : (j1 ? u1.im : ub.im)};
     if (j >= M) uj = zero;
     // w = V^-1 u (one entry per row), then its copy per column
     Cx<R> wi = sq.rowsum(cmul(Vinvs, uj));
@@ -439,28 +360,6 @@ __device__ __forceinline__ void bg_source(const Sq<MP, R>& sq, Cx<R>& B, const C
     Cx<R> Jn;                          // lanes i < K, j >= K: J[i][j - K]
     if constexpr (K == 1) {
         Jn = cmul(sq.colb(Tm, 0), cinv(sq.template at_c<0, 0>(Tm)));
-    } else if constexpr (K >= 3) {
-        Cx<R> q[K][K], adj[K][K], det, r[K];
-        static_for<K>([&](auto ac) {
-            constexpr int a = decltype(ac)::value;
-            r[a] = sq.colb(Tm, a);                                    // Tm[a][j]
-            static_for<K>([&](auto bc) { q[a][decltype(bc)::value] = sq.template at_c<a, decltype(bc)::value>(Tm); });
-        });
-        small_adj<K, R>(q, adj, det);
-        const Cx<R> idet = cinv(det);
-        Cx<R> n[K];
-        static_for<K>([&](auto ac) {
-            constexpr int a = decltype(ac)::value;
-            n[a] = cmul(adj[a][0], r[0]);
-            static_for<K - 1>([&](auto bc) { cfma(n[a], adj[a][decltype(bc)::value + 1], r[decltype(bc)::value + 1]); });
-        });
-        const bool i0 = i == 0, i1 = i == 1, i2 = i == 2;
-        Cx<R> ni;
-        if constexpr (K == 3)
-            ni = Cx<R>{i0 ? n[0].re : (i1 ? n[1].re : n[2].re), i0 ? n[0].im : (i1 ? n[1].im : n[2].im)};
-        else
-            ni = Cx<R>{i0 ? n[0].re : (i1 ? n[1].re : (i2 ? n[2].re : n[3].re)), i0 ? n[0].im : (i1 ? n[1].im : (i2 ? n[2].im : n[3].im))};
-        Jn = cmul(ni, idet);
     } else {
         const Cx<R> t00 = sq.template at_c<0, 0>(Tm), t01 = sq.template at_c<0, 1>(Tm), t10 = sq.template at_c<1, 0>(Tm),
                     t11 = sq.template at_c<1, 1>(Tm);
@@ -485,9 +384,7 @@ template <int MP, typename R, int K>
 __device__ __forceinline__ void bg_core(const Sq<MP, R>& sq, Cx<R>& B, const Cx<R>& C, const Cx<R> (&V)[K], const Cx<R> (&Vinv)[K], Cx<R> Tm,
                                         Cx<R> Bt, int M) {
     bg_source<MP, R, K, 0>(sq, B, C, V[0], Vinv[0], Tm, Bt, M);
-    if constexpr (K >= 2) bg_source<MP, R, K, 1>(sq, B, C, V[1], Vinv[1], Tm, Bt, M);
-    if constexpr (K >= 3) bg_source<MP, R, K, 2>(sq, B, C, V[2], Vinv[2], Tm, Bt, M);
-    if constexpr (K >= 4) bg_source<MP, R, K, 3>(sq, B, C, V[3], Vinv[3], Tm, Bt, M);
+    if constexpr (K == 2) bg_source<MP, R, K, 1>(sq, B, C, V[1], Vinv[1], Tm, Bt, M);
 }
 
 // everything in one call (the stand-alone update kernels)

@@ -411,9 +411,12 @@ def test_pca_subspace_on_device(oa, shape):
 
 @pytest.mark.parametrize("shape", [(96, 5, 11, 3), (80, 3, 9, 9), (72, 6, 13, 1), (64, 4, 16, 5), (50, 7, 7, 7), (90, 19, 5, 2),
                                    (90, 21, 8, 3), (64, 9, 8, 4), (70, 5, 8, 5), (100, 12, 8, 8), (60, 7, 7, 4), (64, 5, 12, 12),
-                                   (70, 4, 16, 16), (60, 3, 10, 10), (66, 2, 15, 15)])
+                                   (70, 4, 16, 16), (60, 3, 10, 10), (66, 2, 15, 15), (80, 6, 6, 4), (75, 5, 8, 6), (90, 4, 5, 3),
+                                   (85, 5, 6, 3), (77, 6, 7, 5)])
 def test_odd_shapes_against_oracle(oa, shape):
-    """channel counts without a golden fixture (incl. the 9..16-channel covariance kernels), default arithmetic"""
+    """channel counts without a golden fixture (incl. the 9..16-channel covariance kernels) and every form of the per-bin update
+    -- structured chain (1-2 sources + background), Gram form (3 and more sources + background), maintained inverse (determined, up
+    to 8 and 9..16 channels) -- in the default arithmetic"""
     T, F, M, K = shape
     X = orc.synth_iid(T, F, M, seed=sum(shape))
     for model in ("laplace", "gauss"):
