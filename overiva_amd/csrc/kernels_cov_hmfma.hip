@@ -55,11 +55,7 @@ struct HmOps {
 template <bool FIRST, bool M16>
 __device__ __forceinline__ void hm_read_issue(unsigned base, const unsigned (&ao)[9], unsigned a_w, HmOps& o, float& w) {
     if constexpr (FIRST) {
-#ifdef OIVA_HM_NODMA
-        asm volatile("ds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w) : "memory");
-#else
         asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w), "n"(3 * (kHmStages - 1)) : "memory");
-#endif
     } else {
         asm volatile("ds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w) : "memory");
     }
@@ -98,11 +94,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
                                                               double* __restrict__ Vpart, int T, int F, int M, int Mv, int K, int tc) {
     constexpr int kRingBytes = kWaves * kHmStages * kHmStage;
     constexpr int kScratchBytes = (int)sizeof(float) * kHmChunk * kHmLdsStride;
-#ifdef OIVA_HM_LDSPAD
-    __shared__ float4 ring[72 * 1024 / 16];
-#else
     __shared__ float4 ring[(kRingBytes > kScratchBytes ? kRingBytes : kScratchBytes) / 16 + 1];
-#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -181,13 +173,8 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
                 a[2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, im, a[2 * c], 0, 0, 0);
             } else if (c <= MH) {                             // (wave-uniform)
                 const float2 x = o.x[c - 1];
-#ifdef OIVA_HM_NOVALU
-                a[2 * c - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, o.row.x, a[2 * c - 1], 0, 0, 0);
-                a[2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, o.row.y, a[2 * c], 0, 0, 0);
-#else
                 a[2 * c - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, x.y, o.row.x * x.x), a[2 * c - 1], 0, 0, 0);     // Re x_n conj x_m
                 a[2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, x.x, -(o.row.x * x.y)), a[2 * c], 0, 0, 0);         // Im x_n conj x_m
-#endif
             }
         });
     };
@@ -208,9 +195,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     issue(1, 1);
     issue(2, 2);
     for (int i = 0; i < nstages; ++i) {
-#ifndef OIVA_HM_NODMA
         issue(i + 3, (i + 3) & 3);
-#endif
         stage(i & 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the DMA queue before the ring becomes reduction scratch
@@ -222,14 +207,6 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     //      re / im are compile-time and only (source row, channel) come from the lane.
     float* lds = reinterpret_cast<float*>(ring);
     const int NA = Mv * Mv;
-#ifdef OIVA_HM_NOEPI
-    {
-        float t = 0.f;
-        for (int h = 0; h < 2; ++h) for (int g2 = 0; g2 < 17; ++g2) for (int r = 0; r < 4; ++r) t += acc[h][g2][r];
-        if (t == 1.2345e30f) Vpart[tid] = t;
-        return;
-    }
-#endif
     double* vout = Vpart + (((size_t)blockIdx.y * F + f0) * K + 4 * q + wave) * NA;
     const bool live = 4 * q + wave < K && n < M;
 #pragma unroll
@@ -266,9 +243,6 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
                 pos = herm_pair_index(Mv, i, j) + im;
                 if (im && mm < n) s = -s;                                 // Im(x_i conj x_j) = -Im(x_j conj x_i)
             }
-#ifdef OIVA_HM_NOSTORE
-            if (s == 1.2345e300)
-#endif
             vout[pos] = s;
         }
     }
