@@ -262,7 +262,8 @@ def _cov_roofline(shape, mode, cov_ms):
                        "algorithmic_bytes_per_launch": bytes_cov, "hbm_gbs": bytes_cov / sec / 1e9, "avg_launch_ms": cov_ms, "traffic": None,
                        "note": "achieved / frac count ISSUED flops (matrix instructions 2048 each, vector instructions 128) against the 157.3 "
                                "TFLOP/s spec peak, which on CDNA4 the fp32 matrix and vector instructions SHARE (measured: their times add); "
-                               "useful = Hermitian half with each product formed once; naive = SURVEY 8d's 8 K M^2 T F"}
+                               "useful = Hermitian half with each product formed once; naive = SURVEY 8d's 8 K M^2 T F.  avg_launch_ms is the "
+                               "event-bracketed stage: the weights pre-pass (~6 us) + the kernel + the gaps of the bracketing events"}
     if mode != "precise" and k > 4:
         # the Hermitian half on the vector ALU, 32 lanes per (bin, frame), every source in one pass: bound by fp32 arithmetic
         # (cfg5's roofline is the 157.3 TFLOP/s fp32 peak, which the packed vector ALU shares with the matrix cores)
