@@ -28,6 +28,12 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
 import argparse
 import json
 import os
+
+# The host driver of this platform shares device memory between processes through dmabuf only (RCCL, the library's own
+# exchanges): the variable has to be in the environment before this process's first GPU call, whatever launched it
+# (torch.distributed.run, the driver, a shell).  Nothing above this line touches a GPU.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import signal
 import subprocess
 import sys
@@ -684,20 +690,45 @@ def run_sharded(args):
             cov_ms = eng.plan.t_time_stage("weighted_cov", 20)
             stream.synchronize()
             spg = 8            # iterations per captured graph (kernels + the RCCL all-gather)
-            # Capturing RCCL collectives in a graph was verified with one rank only (this pool has 1-GPU boxes), so
-            # the multi-rank default is eager launches (host cost per step ~45 us < device time); --graph 2 opts in.
-            if args.graph >= 2 and args.steps >= spg and xchg.name == "collective":
+            # The eager loop costs the host ~45 us per step against 30-50 us of device time at 8 GPUs, so the collective path
+            # replays captured graphs (kernels + all-gather) -- after the capture has proved itself on THIS platform with THESE
+            # ranks: spg steps eagerly, then from the same start one replay; every rank must see the same bits.  Anything
+            # else (capture refused, a rank that differs) leaves the run eager, with the reason in ranks.graph_refused.
+            # (--graph 0: never)
+            graph_refused = None
+            if args.graph >= 1 and args.steps >= spg and xchg.name == "collective" and args.backend == "nccl":
+                why = None
                 try:
+                    eng.set_w(None)
+                    for _ in range(spg):
+                        step()
+                    stream.synchronize()
+                    w_eager = eng.get_w()
+                    eng.set_w(None)
+                    stream.synchronize()
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph, stream=stream):
                         for _ in range(spg):
                             step()
                     graph.replay()
                     stream.synchronize()
+                    w_graph = eng.get_w()
+                    if not np.array_equal(w_eager, w_graph):
+                        why = "a replayed graph of the collective path differs from the eager steps"
                 except Exception as e:  # capture of the collective not supported: stay eager
-                    if rank == 0:
-                        print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); eager", file=sys.stderr)
+                    why = f"{type(e).__name__}: {e}"
+                notes = [None] * world
+                dist.all_gather_object(notes, why)
+                if any(n is not None for n in notes):
+                    graph_refused = "; ".join(f"rank {r}: {n}" for r, n in enumerate(notes) if n is not None)
                     graph = None
+                    if rank == 0:
+                        print(f"[bench] graph replay of the collective path not used ({graph_refused}); eager", file=sys.stderr)
+                eng.set_w(None)
+                for _ in range(args.warmup):
+                    step()
+                stream.synchronize()
+            breakdown["graph_refused"] = graph_refused
             dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -743,6 +774,14 @@ def run_sharded(args):
             out["config"]["parallelism"] = (f"bins sharded over {world} GPU(s); four kernels per iteration replayed from hipGraphs, the partial source "
                                             "powers exchanged inside the activation kernel by peer stores over xGMI (no collective, no host call in the loop)")
     out["cpu_baseline"] = None      # reported at N = 1 only
+    # a fast exchange that was asked for (or implied by `auto`) and refused is a DEGRADED run: said at the top level, not
+    # only among the per-rank details
+    degraded = None if (resident or fused or args.exchange in ("collective", "push")) else (fused_refused or resident_refused or "refused")
+    if args.exchange == "push" and exchange_name != "push":
+        degraded = exchange_fallback or "push exchange refused"
+    out["exchange_degraded"] = degraded
+    if degraded and rank == 0:
+        print(f"[bench] DEGRADED: the in-kernel exchange was not used ({degraded}); this line measures the collective path", file=sys.stderr)
     out["ranks"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                     "exchange": "resident" if resident else ("fused" if fused else exchange_name),
                     "exchange_requested": args.exchange,

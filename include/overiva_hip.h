@@ -187,6 +187,10 @@ int oiva_plan_set_w_eig(oiva_plan *p);
 int oiva_plan_get_w(oiva_plan *p, void *W_host, int f64);
 
 int oiva_plan_sync(oiva_plan *p);
+/* A copy of the demixing state W_hat on the device, made / brought back on the plan's stream (asynchronous, ordered with the
+ * iterations around it): what a caller of the in-kernel exchanges keeps to fall back on when a rank does not deliver. */
+int oiva_plan_save_w(oiva_plan *p);
+int oiva_plan_restore_w(oiva_plan *p);
 
 /*
  * Measurement.  Runs n iterations bracketed by HIP events on the plan's stream and, when
@@ -282,8 +286,11 @@ int oiva_plan_resident_connect(oiva_plan *p, struct oiva_xchg *x);
  * rank's buffer (peer stores over xGMI), polls its own buffer for the other ranks' words and adds the ranks' sums in rank
  * order (overiva.py:152-155; the same bits of r on every rank).  No collective, no stream wait, no host in the loop:
  * oiva_plan_iterate works on a shard (F < F_total) and replays captured graphs of four kernels per iteration.  Every rank
- * must run the same number of iterations.  A wait that gives up (default 2 s) is reported by the next oiva_plan_sync /
- * oiva_plan_get_w (OIVA_ERR_STATE).  x = NULL disconnects.
+ * must run the same number of iterations.  Connecting zeroes the rank's own gather buffer and restarts the epochs: the ranks
+ * must rendezvous (any barrier of the host side) between their connects and their first iteration.  A wait that gives
+ * up (default 2 s) is reported by the next oiva_plan_sync / oiva_plan_get_w / oiva_plan_demix* (OIVA_ERR_STATE); the demixing
+ * matrices of the iterations since are undefined: oiva_plan_save_w before, oiva_plan_restore_w after.  x = NULL disconnects
+ * and clears the condition.
  *   oiva_plan_fused_loopback: world >= 2: ONE GPU runs that exchange against itself (own buffer, the other ranks' sums are
  *                             zeros: the result is the single-GPU one up to the association of the sum); 0 / 1: off.
  *   oiva_plan_fused_debug   : test hooks -- time-out of a wait in milliseconds (0: default); stall != 0: in loop-back the other

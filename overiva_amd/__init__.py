@@ -7,7 +7,13 @@ Host code is Python (as the reference is); all arithmetic on the path runs in ha
 kernels reached through the C ABI of ``liboveriva_hip.so`` (``include/overiva_hip.h``).  There is
 no CPU fallback: without the built library the calls raise ``HipLibraryMissing``.
 """
-from ._lib import HipError, HipLibraryMissing  # noqa: F401
+from . import _lib as _lib_mod
+
+# The host driver of this platform shares device memory between processes through dmabuf only (RCCL, the library's own
+# exchanges): the variable must be in the environment BEFORE the process's first GPU call, whatever launched the process.
+_lib_mod._set_ipc_env_at_import()
+
+from ._lib import HipError, HipLibraryMissing  # noqa: E402,F401
 from .auxiva_pca import auxiva_pca  # noqa: F401
 from .ive import ogive  # noqa: F401
 from .overiva import get_device, get_precision, last_solver_info, overiva, set_device, set_precision  # noqa: F401

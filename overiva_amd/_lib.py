@@ -67,6 +67,8 @@ SIGNATURES = {
     "oiva_xchg_destroy": [_vp],
     "oiva_plan_get_w": [_vp, _vp, _i],
     "oiva_plan_sync": [_vp],
+    "oiva_plan_save_w": [_vp],
+    "oiva_plan_restore_w": [_vp],
     "oiva_plan_iterate_timed": [_vp, _i, _fp, _fp],
     "oiva_plan_get_cov_splits": [_vp, C.POINTER(_i)],
     "oiva_plan_set_cov_splits": [_vp, _i],
@@ -143,13 +145,15 @@ def require_dmabuf_ipc(what):
     """The host driver of this platform exports device memory through dmabuf only: ``hipIpcGetMemHandle`` (the push
     exchange and the X-resident kernel's exchange between processes, RCCL, device tensors shared across processes) fails
     with "invalid argument" unless ``HSA_ENABLE_IPC_MODE_LEGACY=0`` is in the environment BEFORE the process's first GPU
-    call.  Importing the package does not touch the environment; the multi-process exchanges call this when they are asked
-    for: it sets the variable if it is unset (effective only if HIP has not initialised yet -- launchers such as
-    ``bench.py --gpus N`` export it for their ranks) and warns when it holds another value."""
+    call.  ``import overiva_amd`` sets the variable when it is unset (``__init__.py``: importing torch does not start the
+    GPU runtime, so a process that imports the package before its first GPU call is safe under ANY launcher); the
+    multi-process exchanges call this when they are asked for and warn when the runtime had started without it, or when
+    the variable holds another value.  Returns None when all is well, else the reason (``exchange_degraded`` of bench.py)."""
     import warnings
 
     cur = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
-    if cur is None:
+    why = None
+    if cur is None or _IPC_ENV_SET_LATE:
         os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         try:
             import torch
@@ -157,11 +161,34 @@ def require_dmabuf_ipc(what):
             started = torch.cuda.is_initialized()
         except Exception:
             started = False
-        if started:
-            warnings.warn(f"{what}: HSA_ENABLE_IPC_MODE_LEGACY=0 was not in the environment when the GPU runtime started; "
-                          "exporting device memory to other processes may fail (export it before launching)")
+        if (started and cur is None) or _IPC_ENV_SET_LATE:
+            why = (f"{what}: HSA_ENABLE_IPC_MODE_LEGACY=0 was not in the environment when the GPU runtime started; "
+                   "exporting device memory to other processes may fail (import overiva_amd, or export the variable, before "
+                   "the first GPU call)")
     elif cur != "0":
-        warnings.warn(f"{what}: HSA_ENABLE_IPC_MODE_LEGACY={cur!r}; this platform's driver supports dmabuf IPC (=0) only")
+        why = f"{what}: HSA_ENABLE_IPC_MODE_LEGACY={cur!r}; this platform's driver supports dmabuf IPC (=0) only"
+    if why:
+        warnings.warn(why)
+    return why
+
+
+_IPC_ENV_SET_LATE = False
+
+
+def _set_ipc_env_at_import():
+    """``import overiva_amd``: HSA_ENABLE_IPC_MODE_LEGACY=0 unless the caller chose a value; remembers when the GPU runtime of
+    this process was already running (the variable is read once, at its start)"""
+    global _IPC_ENV_SET_LATE
+    if "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ:
+        return
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import sys
+
+    t = sys.modules.get("torch")
+    try:
+        _IPC_ENV_SET_LATE = bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        _IPC_ENV_SET_LATE = False
 
 
 def check(rc):

@@ -4,6 +4,7 @@ hipcc cross-compiles without a GPU, so this runs in the build container; the res
 with the source tree to the GPU box.
 """
 import os
+import shutil
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -65,8 +66,9 @@ def _compile(src, extra=()):
                 else:
                     rest.append(line)
             # (clang prints a source excerpt + caret under every remark: drop those lines too)
-            shown = [l for l in rest if l.strip() and not l.lstrip().startswith(("__global__", "^", "|")) and "remarks generated" not in l
-                     and not l.lstrip()[:1].isdigit()]
+            # (... and the "In file included from" trail clang prints in front of a remark that sits in an included file)
+            shown = [l for l in rest if l.strip() and not l.lstrip().startswith(("__global__", "^", "|", "In file included from"))
+                     and "remarks generated" not in l and not l.lstrip()[:1].isdigit()]
             with open(os.path.splitext(obj)[0] + ".usage.txt", "w") as f:
                 f.writelines(remarks)
             if shown:
@@ -104,7 +106,11 @@ def build_library(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     if force:
         for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+            path = os.path.join(OBJ, f)
+            if os.path.isdir(path):                      # (variant_* directories of tools/build_variant.py)
+                shutil.rmtree(path)
+            else:
+                os.remove(path)
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if force or _stale(LIB, objs):

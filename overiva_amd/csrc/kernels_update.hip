@@ -488,13 +488,22 @@ __global__ __launch_bounds__(kBlock) void update_det_kernel(UpdateArgs a) {
             const Cx<R> ui = sq.template rowb_c<s>(C);                 // u_i = C[i][s]
             const Cx<R> uj = sq.at(C, j, s);                           // u_j
             const Cx<R> wi = sq.rowsum(cmul(Vinv, uj));                // w = V^-1 u (not yet normalised), one entry per row
-            // y = w^H C, one entry per column;  y_s = w^H u = w^H V w =: d  (overiva.py:185; real)
+            // d = w^H V_s w from V_s itself, as the reference forms it (overiva.py:185), and y_s = w^H u as its own (complex)
+            // quantity: with the exact w both are the same number, and round 4 used Re(y_s) for both -- on a W_hat that is
+            // not adapted to V_s (first iterations) and cond(V) = 1e10 that put the result 2e-4 from the reference's, whose
+            // own sensitivity there is 8e-7; with the two kept apart the form stays at that sensitivity up to cond 1e12
+            // (tests/test_update_forms.py; a step of iterative refinement on top changed nothing and is not done)
+            const Cx<R> ti = sq.rowsum(cmul(V, sq.transp(wi)));        // t = V w, one entry per row (0 outside M)
+            // d = w^H V w (overiva.py:185; real)
+            const R d = sq.allsum(j == 0 ? wi.re * ti.re + wi.im * ti.im : R(0));
+            // y = w^H C, one entry per column;  y_s = w^H u  (= d for the exact w)
             const Cx<R> t = cmul(Cx<R>{wi.re, -wi.im}, C);
             Cx<R> y = {sq.colsum(t.re), sq.colsum(t.im)};
-            const R d = sq.template rowb_c<s>(y.re);
-            const R sc = fast_rsqrt(d), rd = fast_rcp(d);
-            // with w' = w / sqrt(d):  C' = C - u (w'^H C - e_s^T) / (w'^H u) = C - (u / d) (y - sqrt(d) e_s^T)
-            const Cx<R> g = {ui.re * rd, ui.im * rd};
+            const Cx<R> ys = sq.template rowb_c<s>(y);
+            const R sc = fast_rsqrt(d);
+            // row s of W_hat^H becomes w'^H, w' = w / sqrt(d): by Sherman-Morrison (exact for ANY w)
+            //   C' = C - u (w'^H C - e_s^T) / (w'^H u) = C - (u / y_s) (y - sqrt(d) e_s^T)
+            const Cx<R> g = cmul(ui, cinv(ys));
             if (j == s) y.re -= d * sc;
             cfms(C, g, y);
             // (off the chain) row s of W_hat^H = w'^H

@@ -583,6 +583,9 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
                 if (sgn[e] != 0.f) Vi[e].im = s.pk[off[e] + 1] * R(sgn[e]) * invT;
             }
         }
+        C2<R> Vs[4];                                             // V itself, for the residual below
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Vs[e] = Vi[e];
         herm_inverse(Vi);
         // u = column src of C: u_i for the row, u_c for the lane's four columns (through LDS)
         const int se = src >> 2, sq = src & 3;
@@ -595,15 +598,29 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
         }
         wave_lds_sync();
         const C2<R> ui = s.w[i];
-        // w = V^-1 u (not yet normalised): row i from this lane's four columns, then over the quad
-        R wr = R(0), wim = R(0);
+        // row i of (matrix held four columns per lane) x (vector by index in LDS), on every lane of the quad
+        auto matvec = [&](const C2<R> (&A)[4], const C2<R> (&x)[N]) -> C2<R> {
+            R vr = R(0), vi = R(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const C2<R> uc = s.w[4 * e + q];
-            wr += Vi[e].re * uc.re - Vi[e].im * uc.im;
-            wim += Vi[e].re * uc.im + Vi[e].im * uc.re;
-        }
-        const C2<R> wi = {quad_sum(wr), quad_sum(wim)};
+            for (int e = 0; e < 4; ++e) {
+                const C2<R> xc = x[4 * e + q];
+                vr += A[e].re * xc.re - A[e].im * xc.im;
+                vi += A[e].re * xc.im + A[e].im * xc.re;
+            }
+            return {quad_sum(vr), quad_sum(vi)};
+        };
+        auto publish = [&](C2<R> (&x)[N], C2<R> v) {             // x[i] = v (equal within the quad)
+            wave_lds_sync();
+            if (q == 0) x[i] = v;
+            wave_lds_sync();
+        };
+        // w = V^-1 u (not yet normalised)
+        const C2<R> wi = matvec(Vi, s.w);
+        publish(s.w, wi);
+        // t = V w for d = w^H V w as the reference forms it (overiva.py:185) -- not Re(w^H u): see update_det_kernel
+        const C2<R> ti = matvec(Vs, s.w);
+        // d = w^H V w (overiva.py:185; real)
+        const R d = wave_sum16(wi.re * ti.re + wi.im * ti.im);
         // y = w^H C: column sums over the 16 rows (lanes of equal q)
         C2<R> y[4];
 #pragma unroll
@@ -611,20 +628,17 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
             const C2<R> x = cmul(cconj(wi), C[e]);
             y[e] = {wave_sum16(x.re), wave_sum16(x.im)};
         }
-        // d = y_src (real): held by the lanes q == sq in element se
+        // y_src = w^H u (= d for the exact w): held by the lanes q == sq in element se
         wave_lds_sync();
         if (lane == sq) {
-            const R v = se == 0 ? y[0].re : (se == 1 ? y[1].re : (se == 2 ? y[2].re : y[3].re));
-            s.ppiv = {v, R(0)};
+            const C2<R> v = se == 0 ? y[0] : (se == 1 ? y[1] : (se == 2 ? y[2] : y[3]));
+            s.ppiv = v;
         }
-        if (q == 0) s.w[i] = wi;
         wave_lds_sync();
-        const R d = s.ppiv.re;
-        double rd = __builtin_amdgcn_rcp(d);
-        rd = fma(fma(-d, rd, 1.0), rd, rd);
-        rd = fma(fma(-d, rd, 1.0), rd, rd);
+        const C2<R> ys = s.ppiv;
         const R sc = R(1) / sqrt(d);
-        const C2<R> g = {ui.re * rd, ui.im * rd};
+        // Sherman-Morrison for the new row src of W_hat^H (exact for any w): C' = C - (u / y_src) (y - sqrt(d) e_src^T)
+        const C2<R> g = cmul(ui, cinv_fast(ys));
         const R sqd = d * sc;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -136,7 +136,11 @@ struct oiva_plan {
     int fx_nblk_own = 1, fx_nblk_peer = 1;      // block sums this rank forms / words per other rank's slot
     char* fx_loop_buf = nullptr;                // loop-back: this plan's own gather buffer
     unsigned* fx_state = nullptr;               // [0] give-up flag, [16 ...] one epoch counter per workgroup of the activation kernel
+    unsigned* fx_flag_host = nullptr;           // pinned: fx_state[0] as copied behind the work on the plan's stream (check_fused)
     int fx_timeout_ms = 0, fx_stall = 0;
+    float2* ck_what = nullptr;                  // oiva_plan_save_w: a copy of W_hat (and of its complex128 form) on the device
+    double2* ck_what64 = nullptr;
+    bool ck_valid = false, ck_what64_valid = false;
     hipGraphExec_t graph_exec = nullptr;        // one iteration
     hipGraphExec_t graph_batch_exec = nullptr;  // kGraphBatch iterations
     hipEvent_t ev[2] = {};
@@ -731,6 +735,9 @@ int oiva_plan_destroy(oiva_plan* p) {
     if (p->res_loop_buf) (void)hipFree(p->res_loop_buf);
     if (p->fx_loop_buf) (void)hipFree(p->fx_loop_buf);
     if (p->fx_state) (void)hipFree(p->fx_state);
+    if (p->fx_flag_host) (void)hipHostFree(p->fx_flag_host);
+    if (p->ck_what) (void)hipFree(p->ck_what);
+    if (p->ck_what64) (void)hipFree(p->ck_what64);
     for (auto& ev : p->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
@@ -889,11 +896,14 @@ static int set_w_from_eigenvectors(oiva_plan* p, double* evals_host, bool lapack
     return OIVA_OK;
 }
 
+static int check_fused(oiva_plan* p);
+
 int oiva_plan_demix_dev(oiva_plan* p, int proj_back, void** Y_dev) {
     int rc = check_ready(p);
     if (rc) return rc;
     NEED(Y_dev, OIVA_ERR_ARG, "null output");
     DeviceGuard guard(p->device);
+    if ((rc = check_fused(p))) return rc;
     const size_t row = (size_t)p->F * p->K * sizeof(float2);
     if (!p->Y) HIP_TRY(hipMalloc(&p->Y, row * p->T));
     const float* sp = nullptr;
@@ -980,6 +990,7 @@ int oiva_plan_demix(oiva_plan* p, void* Y_host, long long row_pitch_bytes, int p
     const size_t row = (size_t)p->F * p->K * sizeof(float2);
     const size_t pitch = row_pitch_bytes > 0 ? (size_t)row_pitch_bytes : row;
     NEED(pitch >= row, OIVA_ERR_ARG, "row pitch smaller than one frame of this plan's bins");
+    if ((rc = check_fused(p))) return rc;
     if (!p->Y) HIP_TRY(hipMalloc(&p->Y, row * p->T));
     const float* sp = nullptr;
     if (proj_back) {
@@ -1019,15 +1030,15 @@ int oiva_plan_demix_c128(oiva_plan* p, void* Y_host, long long row_pitch_bytes, 
     return OIVA_OK;
 }
 
-static int check_fused(oiva_plan* p);
-
 int oiva_plan_get_w(oiva_plan* p, void* W_host, int f64) {
     NEED(p && W_host, OIVA_ERR_ARG, "null argument");
     NEED(p->have_w, OIVA_ERR_STATE, "demixing matrix not set");
     DeviceGuard guard(p->device);
     const int F = p->F, M = p->M, K = p->K;
+    int rc = check_fused(p);
+    if (rc) return rc;
     std::vector<double2> wh;
-    int rc = download_what(p, wh);
+    rc = download_what(p, wh);
     if (rc) return rc;
     bool finite = true;
     for (int f = 0; f < F; ++f)
@@ -1045,14 +1056,19 @@ int oiva_plan_get_w(oiva_plan* p, void* W_host, int f64) {
     return OIVA_OK;
 }
 
-// the in-kernel exchange of the four-launch path gave up waiting for a rank (recorded on the device, looked at here)
+// the in-kernel exchange of the four-launch path gave up waiting for a rank: recorded on the device, looked at by everything
+// that hands results to the caller (sync, get_w, the demix entry points).  The flag is copied into a pinned word behind the
+// work already queued on the plan's stream and read after ONE wait for that stream.
 static int check_fused(oiva_plan* p) {
-    if (!p->fx_state) return OIVA_OK;
-    unsigned code = 0;
-    HIP_TRY(hipMemcpy(&code, p->fx_state, sizeof(code), hipMemcpyDeviceToHost));
+    if (!p->fx_state || !p->fx_on) return OIVA_OK;
+    if (!p->fx_flag_host) HIP_TRY(hipHostMalloc((void**)&p->fx_flag_host, sizeof(unsigned), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(p->fx_flag_host, p->fx_state, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    const unsigned code = *p->fx_flag_host;
     if (code != 0)
         return fail(OIVA_ERR_STATE, "the exchange inside the activation kernel gave up waiting for a rank's partial powers (workgroup " +
-                                        std::to_string(code - 1) + "): the state of this plan is undefined");
+                                        std::to_string(code - 1) + "): the state of this plan is undefined (oiva_plan_restore_w brings back the "
+                                        "demixing matrices saved by oiva_plan_save_w; oiva_plan_fused_connect(p, NULL) clears the condition)");
     return OIVA_OK;
 }
 
@@ -1061,6 +1077,34 @@ int oiva_plan_sync(oiva_plan* p) {
     DeviceGuard guard(p->device);
     HIP_TRY(hipStreamSynchronize(p->stream));
     return check_fused(p);
+}
+
+int oiva_plan_save_w(oiva_plan* p) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(p->have_w, OIVA_ERR_STATE, "demixing matrix not set");
+    DeviceGuard guard(p->device);
+    const size_t n = (size_t)p->F * p->M * p->M;
+    if (!p->ck_what) HIP_TRY(hipMalloc((void**)&p->ck_what, n * sizeof(float2)));
+    if (!p->ck_what64) HIP_TRY(hipMalloc((void**)&p->ck_what64, n * sizeof(double2)));
+    // on the plan's stream: ordered behind the iterations already queued, in front of the ones that follow
+    HIP_TRY(hipMemcpyAsync(p->ck_what, p->What, n * sizeof(float2), hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->ck_what64, p->What64, n * sizeof(double2), hipMemcpyDeviceToDevice, p->stream));
+    p->ck_what64_valid = p->what64_valid;
+    p->ck_valid = true;
+    return OIVA_OK;
+}
+
+int oiva_plan_restore_w(oiva_plan* p) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    NEED(p->ck_valid, OIVA_ERR_STATE, "nothing saved (oiva_plan_save_w)");
+    DeviceGuard guard(p->device);
+    const size_t n = (size_t)p->F * p->M * p->M;
+    HIP_TRY(hipMemcpyAsync(p->What, p->ck_what, n * sizeof(float2), hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->What64, p->ck_what64, n * sizeof(double2), hipMemcpyDeviceToDevice, p->stream));
+    p->what64_valid = p->ck_what64_valid;
+    p->wscale_pending = false;
+    p->have_w = true;
+    return OIVA_OK;
 }
 
 static int fused_setup(oiva_plan* p) {
@@ -1081,6 +1125,7 @@ int oiva_plan_fused_connect(oiva_plan* p, oiva_xchg* x) {
         p->fx_world = 1;
         p->fx_rank = 0;
         for (auto& g : p->fx_gath) g = nullptr;
+        if (p->fx_state) HIP_TRY(hipMemset(p->fx_state, 0, sizeof(unsigned)));     // a wait that gave up is history now
         return drop_graph(p);
     }
     char* peers[OIVA_XCHG_MAX_RANKS];
@@ -1096,6 +1141,11 @@ int oiva_plan_fused_connect(oiva_plan* p, oiva_xchg* x) {
     NEED((world - 1) * nblk <= kCanonBlocks, OIVA_ERR_ARG, "the activation kernel polls at most 8 words of the other ranks per frame and source (9 ranks of one sum each)");
     int rc = fused_setup(p);
     if (rc) return rc;
+    // the epochs of this connection start at 1 again: words left in the own gather buffer by an earlier connection (tagged
+    // 1 ... n) must not pass for current ones.  The other ranks store into this buffer from their first iteration on, so
+    // the callers rendezvous between connecting and iterating (include/overiva_hip.h; sharded.py does).
+    HIP_TRY(hipMemset(peers[rank], 0, (size_t)2 * world * slot));
+    HIP_TRY(hipDeviceSynchronize());
     p->fx_nblk_own = p->fx_nblk_peer = nblk;
     for (int r = 0; r < OIVA_XCHG_MAX_RANKS; ++r) p->fx_gath[r] = peers[r];
     p->fx_rank = rank;

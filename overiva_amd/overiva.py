@@ -43,8 +43,9 @@ def set_precision(mode):
 def resolve_precision(dtype, n_chan, mode=None, n_src=None):
     """``"auto"`` follows the reference, which computes in the dtype of X (overiva.py:89,126,131): complex128 input ->
     ``"precise"``; complex64 input -> ``"mixed"``: at every supported channel count the covariance pass hands float64 sums of
-    short float32 chains to the float64 per-bin algebra (up to 8 channels: csrc/kernels_cov.hip; 9..16:
-    csrc/kernels_cov_quad.hip, csrc/kernels_cov_half16.hip -- odd counts on a copy of X padded by one zero channel).
+    short float32 chains to the float64 per-bin algebra (up to 8 channels: csrc/kernels_cov.hip, kernels_cov_pair32.hip;
+    9..16 channels: kernels_cov_quad.hip with up to 4 sources, kernels_cov_half16.hip with 5..8, the fp32 matrix cores of
+    kernels_cov_hmfma.hip with 9..16 -- odd counts on a copy of X padded by one zero channel).
     (``n_chan`` and ``n_src`` no longer matter; kept for callers.)"""
     mode = _precision if mode is None else mode
     if mode != "auto":

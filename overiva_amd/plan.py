@@ -199,6 +199,14 @@ class Plan:
     def sync(self):
         _lib.check(self.lib.oiva_plan_sync(self.h))
 
+    def save_w(self):
+        """keep a copy of the demixing state on the device (asynchronous, ordered on the plan's stream)"""
+        _lib.check(self.lib.oiva_plan_save_w(self.h))
+
+    def restore_w(self):
+        """bring back the state kept by ``save_w``"""
+        _lib.check(self.lib.oiva_plan_restore_w(self.h))
+
     # -- knobs --------------------------------------------------------------------------------
     def cov_splits(self):
         n = C.c_int()

@@ -246,8 +246,17 @@ class HipEngine:
         return None
 
     def iterate_fused(self, n):
+        self.plan.save_w()              # (on the stream, in front of the iterations: what a run falls back on, BinShardedSolver.iterate)
         self.plan.iterate(n)
         self.plan.sync()
+
+    def drop_fused(self):
+        """back to the state in front of the last ``iterate_fused`` call, on the plain activation kernel"""
+        self.plan.fused_connect(None)
+        self.plan.restore_w()
+        if getattr(self, "fused_xchg", None) is not None:
+            self.fused_xchg.close()
+            self.fused_xchg = None
 
     def power(self):
         self.plan.power()
@@ -373,10 +382,26 @@ class BinShardedSolver:
                 mine = str(e)
             notes = [None] * self.world
             self.dist.all_gather_object(notes, mine, group=self.group)
+            if not any(m is not None for m in notes):
+                return
+            # a rank did not deliver in time: EVERY rank goes back to the demixing matrices it saved in front of this call,
+            # leaves the in-kernel exchange for good and repeats the n iterations through the collective (a warning and
+            # last_solver_info()["exchange_degraded"] say so; nothing is silently different)
+            import warnings
+
+            why = "; ".join(f"rank {r}: {m}" for r, m in enumerate(notes) if m is not None)
+            undo = None
+            try:
+                with self.engine.stream_ctx():
+                    self.engine.drop_fused()
+            except Exception as e:
+                undo = f"{type(e).__name__}: {e}"
+            self.dist.all_gather_object(notes, undo, group=self.group)
             if any(m is not None for m in notes):
-                raise RuntimeError("sharded iteration (exchange inside the activation kernel) failed: " +
-                                   "; ".join(f"rank {r}: {m}" for r, m in enumerate(notes) if m is not None))
-            return
+                raise RuntimeError("sharded iteration (exchange inside the activation kernel) failed: " + why + "; and the fall-back "
+                                   "to the collective failed too: " + "; ".join(f"rank {r}: {m}" for r, m in enumerate(notes) if m is not None))
+            self.fused, self.fused_refused = False, "gave up during the run, continued on the collective: " + why
+            warnings.warn("overiva_amd: the exchange inside the activation kernel gave up (" + why + "); the run continues on the collective path")
         if self.resident:
             # every rank launches the same n iterations; a launch that gave up (a rank's parts did not arrive) leaves W
             # unchanged on that rank only, so the ranks compare notes before anybody goes on
@@ -424,6 +449,7 @@ class BinShardedSolver:
         _ov._last_info = {"sharded": True, "world": self.world, "resident": getattr(self, "resident", False),
                           "resident_refused": getattr(self, "resident_refused", None),
                           "fused": getattr(self, "fused", False), "fused_refused": getattr(self, "fused_refused", None),
+                          "exchange_degraded": getattr(self, "resident_refused", None) or getattr(self, "fused_refused", None),
                           "exchange": "resident" if getattr(self, "resident", False) else
                           ("fused" if getattr(self, "fused", False) else getattr(self.xchg, "name", None))}
         if getattr(self, "xchg", None) is not None:

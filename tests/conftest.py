@@ -86,6 +86,32 @@ def chaotic(g, model, n_iter):
     return key in g and float(g[key]) > AMP_LIMIT
 
 
+JITTER_LIMIT = 1e-3
+_JITTER = None
+
+
+def c64_jitter(g, model, n_iter):
+    """largest relative change of the REAL reference's complex64 W on this (fixture, model, n_iter) when every sample of X
+    moves by one unit in the last place (tests/golden/make_jitter_golden.py -> c64_jitter.npz), or None"""
+    global _JITTER
+    if _JITTER is None:
+        path = os.path.join(GOLDEN_DIR, "c64_jitter.npz")
+        _JITTER = {}
+        if os.path.exists(path):
+            with np.load(path) as d:
+                _JITTER = {k: float(d[k]) for k in d.files}
+    return _JITTER.get(f"{g['_id']}_{model}_{n_iter}")
+
+
+def c64_diverged(g, model, n_iter):
+    """True when the reference's OWN complex64 run is not reproducible to 1e-3 under a last-bit change of its input (measured
+    on the reference, c64_jitter above): the complex64 counterpart of `chaotic`.  Three non-chaotic rows: e_mix laplace 20
+    (jitter 7.1e-3, floor 1.8e-3), l_mix gauss 5 (6.1e-3 / 3.7e-3), w_mix gauss 20 (5.7e-3 / 2.7e-3).  On such a row the
+    distance from the reference's complex64 result is held to its jitter instead of its floor."""
+    j = c64_jitter(g, model, n_iter)
+    return j is not None and j > JITTER_LIMIT
+
+
 def has_gpu():
     try:
         import torch

@@ -71,6 +71,22 @@ class OracleEngine:
         V = orc.weighted_cov_all(self.X, rinv)
         self.What = orc.ip_update_bin(self.What, V, self.Cx, self.K)
 
+    # the in-kernel exchange of the product engine, as far as the driver sees it: set up by agreement, n iterations per call,
+    # and -- $OIVA_TEST_FUSED_GIVES_UP = a rank -- a wait that gives up on that rank, which leaves garbage on EVERY rank
+    def setup_fused(self, dist, group, rank, world, nblk=1):
+        return None
+
+    def iterate_fused(self, n):
+        import torch.distributed as dist
+
+        self._saved = self.What.copy()
+        self.What = self.What * np.nan
+        if os.environ.get("OIVA_TEST_FUSED_GIVES_UP") == str(dist.get_rank()):
+            raise RuntimeError("the exchange inside the activation kernel gave up waiting (test)")
+
+    def drop_fused(self):
+        self.What = self._saved
+
     def demix(self, proj_back):
         from oracle import overiva_oracle as orc
 
@@ -109,7 +125,8 @@ def main():
     X = orc.synth_iid(T, F, M, seed=11)
     rng = np.random.default_rng(12)
     W0 = np.eye(M, K)[None] + 0.1 * (rng.standard_normal((F, M, K)) + 1j * rng.standard_normal((F, M, K)))
-    s = BinShardedSolver(T, F, M, K, model, engine_factory=OracleEngine)
+    s = BinShardedSolver(T, F, M, K, model, engine_factory=OracleEngine, exchange="fused" if os.environ.get("OIVA_TEST_FUSED_GIVES_UP") else None)
+    assert s.fused == bool(os.environ.get("OIVA_TEST_FUSED_GIVES_UP"))
     assert s.f1 - s.f0 >= F // world
     s.set_x(X)
     s.covariance()
@@ -131,6 +148,8 @@ def main():
         dist.destroy_process_group()
         return
     W = s.get_w()
+    if os.environ.get("OIVA_TEST_FUSED_GIVES_UP"):
+        assert not s.fused and "gave up" in s.fused_refused
     s.close()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), Y=Y, W=W, Cx=Cx, f0=s.f0, f1=s.f1)
     dist.barrier()

@@ -106,6 +106,12 @@ BIG_CASES = [
     ("w", 160, 24, 6, 2),
     ("x", 150, 40, 6, 1),
     ("y", 176, 33, 2, 1),
+    # (round 5) determined 16 x 16 and 15 x 15 from MORE frames than e (64) and t (144): the matrix-core covariance kernel of
+    # configs[4] where the reference's own complex64 run stays reproducible for 20 iterations (tests/golden/c64_jitter.npz)
+    ("ea", 256, 4, 16, 16),
+    ("eb", 1024, 4, 16, 16),
+    ("ta", 256, 5, 15, 15),
+    ("tb", 1024, 3, 15, 15),
 ]
 BIG_ITERS = (1, 5, 20)
 
@@ -241,7 +247,7 @@ def make_big(ref_overiva, ref_pca):
         if only and name not in only[0]:
             continue
         for family in ("iid", "mix"):
-            seed = 2000 + ord(name) + (0 if family == "iid" else 500)
+            seed = 2000 + sum(ord(c) for c in name) + (0 if family == "iid" else 500)
             X64 = make_input(family, T, F, M, K, seed)
             out = {"X": X64, "T": T, "F": F, "M": M, "K": K}
             nonfinite = []

@@ -131,3 +131,51 @@ def test_processes_sharing_one_gpu(oa, tmp_path, world, F, model):
         assert np.array_equal(got["W"], W) and np.array_equal(got["Y"], Y) and np.array_equal(got["cb"], np.stack(seen))
     else:
         assert eW < 2e-5 and eY < 2e-5
+
+
+def test_bench_under_an_external_launcher_without_the_ipc_variable():
+    """`torch.distributed.run ... bench.py --gpus 2` started by SOMEBODY ELSE, with HSA_ENABLE_IPC_MODE_LEGACY
+    absent from the parent's environment: bench.py (and `import overiva_amd`) put it there before their first GPU call, so
+    the ranks can export their gather buffers and `--exchange auto` resolves to the in-kernel exchange (2 ranks x 1024 bins do
+    not fit on chip: `fused`), not silently to the collective; the line says so at the top level"""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("HSA_ENABLE_IPC_MODE_LEGACY", "OIVA_EXCHANGE")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29721", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--backend", "gloo",
+           "--single-device"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ranks"]["exchange_requested"] == "auto"
+    assert d["ranks"]["exchange"] == "fused" and d["exchange_degraded"] is None, (d["ranks"], r.stderr[-3000:])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["graph"] is True
+
+
+def test_save_and_restore_of_the_demixing_state(oa):
+    """oiva_plan_save_w / oiva_plan_restore_w: what a caller of the in-kernel exchanges falls back on -- after a wait that gave
+    up the plan reports it from every reader (sync, get_w, demix), disconnecting clears the condition, the restored state
+    continues on the plain path to the bits of a run that never used the exchange"""
+    T, F, M, K = 300, 64, 4, 2
+    X = orc.synth_iid(T, F, M, seed=2)
+    W0, _ = _run(oa, X, K, "laplace", "mixed", [5])
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision("mixed")
+        p.set_x(X)
+        p.covariance()
+        p.set_w(None)
+        p.fused_loopback(2)
+        p.iterate(2)
+        p.sync()
+        p.save_w()
+        p.fused_debug(timeout_ms=20, stall=True)
+        p.iterate(3)
+        for reader in (p.sync, p.get_w, lambda: p.demix(False)):
+            with pytest.raises(RuntimeError, match="gave up waiting"):
+                reader()
+        p.fused_debug(timeout_ms=0, stall=False)
+        p.fused_loopback(0)                 # off: the condition is history
+        p.restore_w()
+        p.iterate(3)
+        p.sync()
+        assert np.array_equal(p.get_w(np.complex128), W0)

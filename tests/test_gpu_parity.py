@@ -13,8 +13,9 @@ STFT input; the distance is ||a-b||_F / ||b||_F.
     against the reference's OWN complex64 result (``W_c64_*``): ``max(1e-5, 1.5 * floor)`` with floor = distance between
     the reference's complex64 and complex128 results -- the parity claim -- and against the complex128 result
     ``max(that bound, floor)``: never less accurate than the reference's own complex64 arithmetic (achieved: 0.1-0.9
-    floors).  One regime is held to 3 floors instead: rows where the reference's complex64 run has itself left the
-    complex128 trajectory (floor > 1e-3; one row, e_mix laplace 20 iterations -- see test_overiva_matches_reference).
+    floors).  On the three rows where the reference's own complex64 run is not reproducible to 1e-3 under a last-bit change
+    of X (conftest.c64_diverged, measured on the real reference: tests/golden/c64_jitter.npz) "floor" is replaced by that
+    jitter where it is larger -- see test_overiva_matches_reference.
 * ``fast`` arithmetic (float32 per-bin algebra too): 1e-5 on well-conditioned (i.i.d.) input; on mixture-like input a
   documented envelope of FAST_FLOORS reference floors -- an accuracy statement of that mode, not the parity claim.
 
@@ -27,7 +28,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import chaotic, golden_files, golden_ids, need
+from conftest import c64_diverged, c64_jitter, chaotic, golden_files, golden_ids, need
 from oracle import overiva_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -186,6 +187,36 @@ def test_ip_update(oa, golden, model, fp64, rows):
         assert err < 2e-5, (e, err)
 
 
+@pytest.mark.parametrize("cond", [1e8, 1e10, 1e12])
+@pytest.mark.parametrize("M", [3, 4, 6, 8, 12, 16])
+def test_determined_update_on_ill_conditioned_covariances(oa, M, cond):
+    """ADVICE r4: the float64 update of the determined case (update_det_kernel up to 8 channels, update_det16_kernel above;
+    overiva.py:181-186) on covariances of condition number 1e8 .. 1e12 and a W_hat that is not adapted to them, against the
+    oracle's chain (a pivoted solve with W_hat^H V_s per source) from the covariances the device itself formed: within 4 of
+    the reference's OWN sensitivities to a change of V in its last bits.  (Round 4's form was up to 1e3 sensitivities off:
+    tests/test_update_forms.py.)"""
+    from test_update_forms import ill_conditioned_case, reference_sensitivity
+
+    F = 5
+    X, W_in, _, _ = ill_conditioned_case(F, M, cond, seed=M)
+    X = X.astype(np.complex64)
+    T = X.shape[0]
+    rinv = np.random.default_rng(3).gamma(2.0, 1.0, (T, M)).astype(np.float32)
+    with _plan(oa, X, M, mode="precise") as p:
+        Cx = p.get_cx(np.complex128)
+        p.set_w(None)                  # marks the plan ready; state is overwritten next
+        p.t_set_what(W_in)
+        p.t_set_rinv(rinv)
+        p.t_run_weighted_cov()
+        V = p.t_get_v(np.complex128)
+        p.t_run_update()
+        W_out = p.t_get_what(np.complex128)
+    sens, ref = reference_sensitivity(W_in, V, Cx, M)
+    e = orc.rel_err(W_out, ref)
+    print(f"\n[parity] determined update, {M} channels, cond(Cx) {np.max(np.linalg.cond(Cx)):.1e}: {e:.2e} (reference sensitivity {sens:.1e})")
+    assert e < 4 * sens + 1e-12
+
+
 @pytest.mark.parametrize("mode", ["fast", "mixed"])
 def test_j_initialisation(oa, golden, mode):
     """overiva.py:96-98,120-123.  `mixed` (the default arithmetic, float64 solve): 1e-5; `fast` (float32 solve): 1e-5 up to 8
@@ -249,21 +280,22 @@ def test_overiva_matches_reference(oa, golden, model, n_iter, dt):
     from overiva_amd.overiva import resolve_precision
 
     mode = resolve_precision(Xin.dtype, X.shape[2], n_src=K)
-    # Where the reference's OWN complex64 run has left its complex128 trajectory (floor > 100 TOL: e_mix, 16 x 16 from 64
-    # frames, laplace, 20 iterations -- floor 4.3e-5 after 5 iterations, 1.8e-3 after 20) the final distance is the rounding
-    # noise of iteration ~5 times a growth of 40..300 and depends on the DIRECTION of that noise, not its size: on that row the
-    # vector-ALU covariance kernel lands at 0.64 floors, `fast` at 0.8, the matrix-core kernel -- 0.3..0.6 floors at 1, 2 and 5
-    # iterations, the smallest of the three -- at 2.1.  Such rows are held to 3 floors, every other row to 1.
-    diverged = floor is not None and floor > 100 * TOL
+    # One floor against the complex128 result, 1.5 against the complex64 one -- everywhere but on the three rows where the
+    # reference's OWN complex64 run is not reproducible to 1e-3 (conftest.c64_diverged: its W moves by `jitter` when X changes
+    # in the last bit; e_mix laplace 20: jitter 7.1e-3 = 4 floors).  There the yardstick is that jitter: nothing can be pinned
+    # on a result tighter than the result pins itself.
+    yard = floor
+    if floor is not None and c64_diverged(golden, model, n_iter):
+        yard = max(floor, c64_jitter(golden, model, n_iter))
     if mode == "mixed" and floor is not None:
-        b128 = max(b128, (3.0 if diverged else 1.0) * floor)   # never less accurate than the reference's own complex64 arithmetic
+        b128 = max(b128, yard)   # never less accurate than the reference's own complex64 arithmetic
     _log(test="e2e", fixture=golden["_id"], model=model, n_iter=n_iter, input=dt, mode=mode, W_vs_c128=e128,
          Y_vs_c128=eY, W_vs_ref_c64=e64, ref_c64_floor=floor, amp=_amp(golden, model, n_iter), bound_c128=b128)
     print(f"\n[parity] {golden['_id']} {model} n_iter={n_iter} {dt} ({mode}): W vs c128 {e128:.2e} (bound {b128:.1e}), Y {eY:.2e}"
           + (f", W vs reference-c64 {e64:.2e} (floor {floor:.1e})" if floor is not None else ""))
     assert e128 < b128 and eY < b128
     if dt == "c64" and floor is not None:
-        assert e64 < max(TOL, (3.0 if diverged else 1.5) * floor)      # as close to the reference's complex64 run as its own noise allows
+        assert e64 < max(TOL, 1.5 * yard)      # as close to the reference's complex64 run as its own noise allows
 
 
 @pytest.mark.needs('W_c128_{model}_{n_iter}', 'W_c64_{model}_{n_iter}')
@@ -413,64 +445,85 @@ def test_pca_subspace_on_device(oa, shape):
                                    (90, 21, 8, 3), (64, 9, 8, 4), (70, 5, 8, 5), (100, 12, 8, 8), (60, 7, 7, 4), (64, 5, 12, 12),
                                    (70, 4, 16, 16), (60, 3, 10, 10), (66, 2, 15, 15), (80, 6, 6, 4), (75, 5, 8, 6), (90, 4, 5, 3),
                                    (85, 5, 6, 3), (77, 6, 7, 5)])
-def test_odd_shapes_against_oracle(oa, shape):
+@pytest.mark.parametrize("model", ["laplace", "gauss"])
+def test_odd_shapes_against_oracle(oa, shape, model):
     """channel counts without a golden fixture (incl. the 9..16-channel covariance kernels) and every form of the per-bin update
     -- structured chain (1-2 sources + background), Gram form (3 and more sources + background), maintained inverse (determined, up
     to 8 and 9..16 channels) -- in the default arithmetic"""
+    from overiva_amd.overiva import resolve_precision
+
     T, F, M, K = shape
     X = orc.synth_iid(T, F, M, seed=sum(shape))
-    for model in ("laplace", "gauss"):
-        from overiva_amd.overiva import resolve_precision
-
-        mode = resolve_precision(X.dtype, M, n_src=K)
-        Yr, Wr = orc.overiva_staged(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
-        try:
-            Y, W = oa.overiva(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
-            eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
-        except np.linalg.LinAlgError:
-            # a W_hat^H V that is singular in complex64 arithmetic (gauss, 2 bins x 15 channels: the weights 1 / r leave V to a
-            # few frames): the error the reference raises there too (numpy.linalg.solve) -- accepted only where the
-            # reference's own complex64 arithmetic is chaotic (below)
-            assert mode == "mixed"
-            eW = eY = np.inf
-        bound = TOL
-        if mode == "mixed" and max(eW, eY) >= TOL:
-            # complex64 arithmetic on an ill-conditioned case (gauss with 3-5 bins and 10-16 channels): as far from the
-            # complex128 result as the reference's OWN complex64 arithmetic (oracle, reference-faithful form) is -- and
-            # nothing to pin where that arithmetic is itself chaotic
-            with np.errstate(all="ignore"):
-                _, W64 = orc.overiva_faithful(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
-                floor = orc.rel_err(W64, Wr)
-            if not floor < 1e-2:
-                print(f"\n[parity] T{T} F{F} M{M} K{K} {model}: the reference's complex64 arithmetic is chaotic here (floor {floor:.1e}), ours {eW:.1e}")
-                continue
-            bound = max(TOL, 1.5 * floor)       # the same 1.5 floors test_overiva_matches_reference allows complex64 input
-        _log(test="odd_shape", fixture=f"T{T}F{F}M{M}K{K}", model=model, n_iter=4, input="c64", mode=mode, W_vs_c128=eW,
-             Y_vs_c128=eY)
-        print(f"\n[parity] T{T} F{F} M{M} K{K} {model} 4 its ({mode}): W err {eW:.2e} Y err {eY:.2e} (bound {bound:.1e})")
-        assert eW < bound and eY < 2 * bound
+    mode = resolve_precision(X.dtype, M, n_src=K)
+    Yr, Wr = orc.overiva_staged(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
+    try:
+        Y, W = oa.overiva(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
+        eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
+    except np.linalg.LinAlgError:
+        # a W_hat^H V that is singular in complex64 arithmetic (gauss, 2 bins x 15 channels: the weights 1 / r leave V to a
+        # few frames): the error the reference raises there too (numpy.linalg.solve) -- accepted only where the
+        # reference's own complex64 arithmetic is chaotic (below)
+        assert mode == "mixed"
+        eW = eY = np.inf
+    bound = TOL
+    if mode == "mixed" and max(eW, eY) >= TOL:
+        # complex64 arithmetic on an ill-conditioned case (gauss with 3-5 bins and 10-16 channels): as far from the
+        # complex128 result as the reference's OWN complex64 arithmetic (oracle, reference-faithful form) is -- and
+        # nothing to pin where that arithmetic is itself chaotic
+        floor = _c64_floor(lambda: orc.overiva_faithful(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)[1], Wr)
+        if not floor < 1e-2:
+            pytest.skip(f"the reference's complex64 arithmetic is chaotic here (floor {floor:.1e}), ours {eW:.1e}")
+        bound = max(TOL, 1.5 * floor)       # the same 1.5 floors test_overiva_matches_reference allows complex64 input
+    _log(test="odd_shape", fixture=f"T{T}F{F}M{M}K{K}", model=model, n_iter=4, input="c64", mode=mode, W_vs_c128=eW,
+         Y_vs_c128=eY)
+    print(f"\n[parity] T{T} F{F} M{M} K{K} {model} 4 its ({mode}): W err {eW:.2e} Y err {eY:.2e} (bound {bound:.1e})")
+    assert eW < bound and eY < 2 * bound
 
 
-def test_random_shapes_against_oracle(oa):
-    """60 shapes drawn with a fixed seed -- 2..16 channels, 1..M sources, 4..39 bins, 4 M..159 frames, both models, complex64 and
-    complex128 input -- through every dispatch of the covariance and update kernels, 3 iterations on i.i.d. input (where the
-    reference itself is reproducible to 1e-5): W and Y within the north star's 1e-5 of the oracle's complex128 result"""
-    rng = np.random.default_rng(123)
-    worst = 0.0
-    for it in range(60):
+def _random_shapes(n=60, seed=123):
+    rng = np.random.default_rng(seed)
+    out = []
+    for it in range(n):
         M = int(rng.integers(2, 17))
         K = int(rng.integers(1, M + 1))
-        F = int(rng.integers(4, 40))        # (gauss over one or two bins: r = sum_f |y|^2 / F gets arbitrarily small -- conftest.chaotic)
+        F = int(rng.integers(1, 40))
         T = int(rng.integers(4 * M, 160))
-        model = ("laplace", "gauss")[it % 2]
-        X = orc.synth_iid(T, F, M, seed=1000 + it)
-        Yr, Wr = orc.overiva_staged(X, n_src=K, n_iter=3, proj_back=True, model=model, return_filters=True)
-        for dt in (np.complex64, np.complex128):
+        out.append((it, T, F, M, K, ("laplace", "gauss")[it % 2]))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_shapes(), ids=lambda c: f"{c[0]}-T{c[1]}F{c[2]}M{c[3]}K{c[4]}-{c[5]}")
+def test_random_shapes_against_oracle(oa, case):
+    """60 shapes drawn with a fixed seed -- 2..16 channels, 1..M sources, 1..39 bins, 4 M..159 frames, both models, complex64 and
+    complex128 input -- through every dispatch of the covariance and update kernels, 3 iterations on i.i.d. input: W and Y
+    within the north star's 1e-5 of the oracle's complex128 result, or -- where the reference's own complex64 arithmetic
+    (oracle, reference-faithful form) is farther than that from it: gauss over a handful of bins -- within 1.5 of its floors;
+    skipped, visibly, where that arithmetic is itself chaotic (floor > 1e-2) or the algorithm degenerate"""
+    it, T, F, M, K, model = case
+    X = orc.synth_iid(T, F, M, seed=1000 + it)
+    with np.errstate(all="ignore"):
+        try:
+            Yr, Wr = orc.overiva_staged(X, n_src=K, n_iter=3, proj_back=True, model=model, return_filters=True)
+        except np.linalg.LinAlgError:
+            pytest.skip("degenerate for the algorithm itself (singular in complex128)")
+    if not (np.all(np.isfinite(Wr)) and np.all(np.isfinite(Yr))):
+        pytest.skip("degenerate for the algorithm itself (oracle non-finite)")
+    floor = None
+    for dt in (np.complex64, np.complex128):
+        try:
             Y, W = oa.overiva(X.astype(dt), n_src=K, n_iter=3, proj_back=True, model=model, return_filters=True)
             eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
-            worst = max(worst, eW, eY)
-            assert eW < TOL and eY < TOL, ((T, F, M, K), model, dt.__name__, eW, eY)
-    print(f"\n[parity] 60 random shapes x 2 dtypes: worst error {worst:.1e}")
+        except np.linalg.LinAlgError:
+            eW = eY = np.inf          # (accepted only where the reference's own complex64 arithmetic is chaotic, below)
+        bound = TOL
+        if not (eW < TOL and eY < TOL):
+            if floor is None:
+                floor = _c64_floor(lambda: orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=True, model=model, return_filters=True)[1], Wr)
+            if not floor < 1e-2:
+                pytest.skip(f"the reference's complex64 arithmetic is chaotic here (floor {floor:.1e}); ours {eW:.1e} ({dt.__name__})")
+            bound = max(TOL, 1.5 * floor)
+        print(f"\n[parity] random {case[1:]} {dt.__name__}: W err {eW:.2e} Y err {eY:.2e} (bound {bound:.1e})")
+        assert eW < bound and eY < 2 * bound, ((T, F, M, K), model, dt.__name__, eW, eY, floor)
 
 
 @pytest.mark.parametrize("shape", [(5, 1, 1, 1), (17, 3, 2, 1), (33, 70, 3, 3), (5000, 2, 4, 2), (16, 16, 8, 8),
@@ -690,10 +743,10 @@ def test_shard_size_mixture_20_iterations(oa, model):
 @pytest.mark.parametrize("mode", ["mixed", "precise", "fast"])
 def test_cfg5_shape_full_frame_axis(oa, mode):
     """BASELINE.json configs[4] shape at full T with few bins: 8 bins x 4000 frames x 16 mics / 16 src, in every arithmetic
-    -- `mixed` is what bench.py times and overiva() runs on it: the 32-lanes-per-(bin, frame) vector-ALU covariance
-    (cov_half16_kernel, float32 chains over the frame splits, float64 partials), the matrix-core power pass of > 4 sources
-    and the one-wavefront-per-bin 16 x 16 update in float64; `precise`: the float64 form of the same covariance kernel, two
-    passes of eight sources; `fast`: float32 partials' consumer in float32"""
+    -- `mixed` is what bench.py times and overiva() runs on it: cov_hmfma_kernel<true> (all 16 sources on the fp32 matrix
+    cores, Hermitian products by DPP rotation, float32 chains over the frame splits, float64 partials), the matrix-core
+    power pass of > 4 sources and update_det16_kernel<double> (maintained inverse, one wavefront per bin);
+    `precise`: cov_hmfma64_kernel (the same GEMM on the fp64 matrix cores); `fast`: float32 per-bin algebra"""
     T, F, M, K = 4000, 8, 16, 16
     X = orc.synth_iid(T, F, M, seed=5)
     oa.set_precision(mode)
@@ -747,11 +800,14 @@ def test_headline_size_properties(oa):
 @pytest.mark.parametrize("mode", ["mixed", "fast", "precise"])
 def test_cfg5_full_size_properties(oa, mode):
     """2048 bins x 4000 frames x 16 mics / 16 src (BASELINE.json configs[4]) at FULL size, in the geometry and the arithmetic
-    bench.py times (`mixed`: cov_half16_kernel with its frame splits and float64 partials, the matrix-core power pass,
-    update_wave16_kernel in float64 -- one wavefront per bin over 2048 bins) and in the other two modes: invariants that
-    need no oracle, plus the covariances of three bins against the oracle"""
+    bench.py times -- `mixed`: cov_hmfma_kernel<true> (the sources on the fp32 matrix cores, 4 frame splits, float64 partials),
+    power_mfma_kernel, update_det16_kernel<double> (maintained inverse, one wavefront per bin over 2048 bins); `precise`:
+    cov_hmfma64_kernel + the same update; `fast`: cov_hmfma_kernel + update_wave16_kernel<float> -- invariants that need no
+    oracle, the covariances of three bins against the oracle, and the per-bin update of those bins (overiva.py:181-190, all
+    16 sources) against orc.ip_update_bin from the device's own covariances"""
     T, F, M, K = 4000, 2048, 16, 16
     X = orc.synth_iid(T, F, M, seed=2)
+    bins = (0, 1023, 2047)
     with oa.Plan(T, F, M, K, "laplace") as p:
         p.set_precision(mode)
         p.set_x(X)
@@ -762,6 +818,14 @@ def test_cfg5_full_size_properties(oa, mode):
         What = p.t_get_what(np.complex128)
         V = p.t_get_v(np.complex128)                       # covariances of the last iteration, (K, F, M, M)
         W = p.get_w()
+        # the update kernel alone, at this geometry: W_hat as it stands, covariances from given weights, one update
+        Cx = p.get_cx(np.complex128)
+        rinv2 = np.random.default_rng(9).gamma(2.0, 1.0, (T, K)).astype(np.float32)
+        p.t_set_rinv(rinv2)
+        p.t_run_weighted_cov()
+        V2 = p.t_get_v(np.complex128)
+        p.t_run_update()
+        What2 = p.t_get_what(np.complex128)
     assert np.all(np.isfinite(W)) and W.shape == (F, M, K)
     # mean_t r = 1 before the eps floor (overiva.py:158-159), every source
     assert abs(np.mean(1.0 / rinv.astype(np.float64), axis=0) - 1.0).max() < 1e-5
@@ -774,9 +838,15 @@ def test_cfg5_full_size_properties(oa, mode):
     assert np.abs(V[s] - np.conj(np.swapaxes(V[s], 1, 2))).max() < 1e-6 * np.abs(V[s]).max()
     # the covariances of three bins, all 16 sources, against the oracle given the device's own weights
     tol = 1e-6 if mode == "precise" else 5e-6      # (float32 products and chains in `fast` / `mixed`; the weights travel as float32 in all)
-    for f in (0, 1023, 2047):
+    for f in bins:
         ref = orc.weighted_cov_all(X[:, f:f + 1, :], rinv.astype(np.float64))[:, 0]
         assert orc.rel_err(V[:, f], ref) < tol
+    # the update of those bins against the oracle's chain (IP1 solve, normalisation; no background at K = M)
+    for f in bins:
+        ref = orc.ip_update_bin(What[f:f + 1], V2[:, f:f + 1], Cx[f:f + 1], K)
+        e = orc.rel_err(What2[f:f + 1], ref)
+        print(f"\n[parity] cfg5 full size {mode}: update of bin {f} vs oracle {e:.2e}")
+        assert e < (2e-5 if mode == "fast" else 1e-9)
 
 
 @pytest.fixture(scope="module")

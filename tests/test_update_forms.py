@@ -44,6 +44,65 @@ def determined_by_maintained_inverse(W_hat, V):
     return W_hat
 
 
+def herm_inverse_unpivoted(A):
+    """in-place Gauss-Jordan without pivot search, as the kernels invert V_s (update_chain.h: Sq::herm_inverse; real pivots)"""
+    A = A.copy()
+    for k in range(A.shape[1]):
+        d = 1.0 / A[:, k, k].real
+        rkd = A[:, k, :] * d[:, None]
+        ck = A[:, :, k].copy()
+        new = A - ck[:, :, None] * rkd[:, None, :]
+        new[:, k, :] = rkd
+        new[:, :, k] = -ck * d[:, None]
+        new[:, k, k] = d
+        A = new
+    return A
+
+
+def determined_as_the_kernels(W_hat, V, round4=False):
+    """update_det_kernel / update_det16_kernel step by step: unpivoted inverse of V_s, u from the maintained C, d = w^H V_s w
+    from V_s itself (overiva.py:185), C by Sherman-Morrison with the complex y_s = w^H u.
+    round4: the form of round 4, Re(y_s) in both places (equal in exact arithmetic)."""
+    W_hat = W_hat.copy()
+    F, M, _ = W_hat.shape
+    C = np.linalg.inv(_herm(W_hat))
+    for s in range(M):
+        u = C[:, :, s]
+        w = np.einsum("fij,fj->fi", herm_inverse_unpivoted(V[s]), u)
+        y = np.einsum("fi,fij->fj", np.conj(w), C)
+        ys = y[:, s].copy()
+        d = ys.real.copy() if round4 else np.einsum("fi,fij,fj->f", np.conj(w), V[s], w).real
+        W_hat[:, :, s] = w / np.sqrt(d)[:, None]
+        y[:, s] -= np.sqrt(d)
+        C = C - (u / (d if round4 else ys)[:, None])[:, :, None] * y[:, None, :]
+    return W_hat
+
+
+def ill_conditioned_case(F, M, cond, seed):
+    """K = M, a mixture whose covariance has the condition number `cond`, W_hat NOT adapted to V (random, as in the first
+    iterations of a run): the regime where the two-step form loses against the reference's single solve"""
+    rng = np.random.default_rng(seed)
+    T = 8 * M + 7
+    S = rng.normal(size=(T, F, M)) + 1j * rng.normal(size=(T, F, M))
+    U, _ = np.linalg.qr(rng.normal(size=(F, M, M)) + 1j * rng.normal(size=(F, M, M)))
+    Vh, _ = np.linalg.qr(rng.normal(size=(F, M, M)) + 1j * rng.normal(size=(F, M, M)))
+    A = U * np.logspace(0, -0.5 * np.log10(cond), M)[None, None, :] @ Vh
+    X = np.einsum("tfm,fnm->tfn", S, A)
+    Cx = orc.input_covariance(X)
+    W_hat = orc.init_demixing(Cx, M, W0=(rng.normal(size=(F, M, M)) + 1j * rng.normal(size=(F, M, M))))
+    V = orc.weighted_cov_all(X, rng.gamma(2.0, 1.0, (T, M)))
+    return X, W_hat, V, Cx
+
+
+def reference_sensitivity(W_hat, V, Cx, K, seed=5):
+    """how far the reference's own chain moves when V changes in its last bits (relative 1e-16)"""
+    rng = np.random.default_rng(seed)
+    ref = orc.ip_update_bin(W_hat, V, Cx, K)
+    Vp = V * (1 + 1e-16 * rng.standard_normal(V.shape))
+    Vp = 0.5 * (Vp + _herm(Vp))
+    return orc.rel_err(orc.ip_update_bin(W_hat, Vp, Cx, K), ref), ref
+
+
 def overdetermined_by_gram_form(W_hat, V, Cx, K):
     """K < M:  column s of (W_hat^H)^-1 = P G^-1 e_s with P = Cx W, G = W^H Cx W;  w = V_s^-1 c, w /= sqrt(c^H w);  J once, from the
     final W (overiva.py:96-98)."""
@@ -81,3 +140,20 @@ def test_update_with_background_through_the_gram_form(shape):
     W = W_hat[:, :, :K]
     G = _herm(W) @ Cx @ W
     assert np.allclose(C[:, :, :K], Cx @ W @ np.linalg.inv(G), atol=1e-9)
+
+
+@pytest.mark.parametrize("cond", [1e8, 1e10, 1e12])
+@pytest.mark.parametrize("M", [4, 8, 16])
+def test_determined_update_on_ill_conditioned_covariances(M, cond):
+    """the maintained-inverse form, with the unpivoted inverse the kernels use, on cond(Cx) = 1e8 .. 1e12 and a
+    W_hat that is not adapted to V.  Round 4's form (Re(w^H u) as the normalisation AND as the Sherman-Morrison denominator)
+    is up to 1e3 reference sensitivities off there; with d = w^H V w from V itself and the complex w^H u as the denominator
+    (what the kernels do now) it stays within 4 sensitivities"""
+    X, W_hat, V, Cx = ill_conditioned_case(6, M, cond, seed=M)
+    sens, ref = reference_sensitivity(W_hat, V, Cx, M)
+    e_r4 = orc.rel_err(determined_as_the_kernels(W_hat, V, round4=True), ref)
+    e = orc.rel_err(determined_as_the_kernels(W_hat, V), ref)
+    print(f"\nM{M} cond {cond:.0e}: reference sensitivity {sens:.1e}, round-4 form {e_r4:.1e}, current form {e:.1e}")
+    assert e < 4 * sens + 1e-13
+    if M >= 8 and cond >= 1e10:
+        assert e_r4 > 50 * sens        # (what the advisor measured: the reason for the change)
