@@ -131,9 +131,18 @@ int oiva_plan_update(oiva_plan *p, const void *parts_dev, int nparts);
 /*
  * Epilogue: Y = demix(X, W) as (T, F, K) complex64 (overiva.py:192-195), optionally scaled by
  * projection back onto channel 0 (overiva.py:197-199; also the callback payload of :142-148).
- * row_pitch_bytes as in set_x_host (0 = dense).  Synchronous.
+ * row_pitch_bytes as in set_x_host (0 = dense).  Synchronous.  Outputs of more than a few MB leave in slabs of frames:
+ * slab k is computed while slab k - 1 crosses PCIe into a pinned ring and slab k - 2 is moved into Y_host by a small pool
+ * of copy threads ($OIVA_IO_THREADS, default min(8, cores / 2); $OIVA_DEMIX_IO = legacy | ring | register, see
+ * csrc/plan.hip demix_to_host).  A Y_host whose pages are already faulted in is served much faster than a fresh
+ * allocation: oiva_host_prefault does that, from the pool's threads, e.g. while the iterations run.
  */
 int oiva_plan_demix(oiva_plan *p, void *Y_host, long long row_pitch_bytes, int proj_back);
+/* Bytes of output per slab of the hand-over above (0: the default, 8 MB).  Test hook. */
+int oiva_plan_set_io_slab(oiva_plan *p, long long bytes);
+/* Fault the pages of [ptr, ptr + bytes) in for writing, contents unchanged, using the library's copy threads.  Blocking;
+ * callable from any thread (overiva() runs it beside the upload of X and the iterations on the array it will return). */
+int oiva_host_prefault(void *ptr, long long bytes);
 /* Same, but Y stays on the device: *Y_dev is the plan's own (T, F, K) complex64 buffer, valid until the next demix of
  * this plan or its destruction.  Hand it to oiva_plan_set_x_dev of another plan to chain two solves without a host
  * round trip (the PCA front-end of auxiva_pca.py:79-87).  Synchronous. */
@@ -222,6 +231,11 @@ int oiva_plan_set_pow_splits(oiva_plan *p, int nsplit);
 int oiva_plan_set_cov_hmfma(oiva_plan *p, int enable);
 /* Replay the iteration from a captured hipGraph instead of eager launches (default off). */
 int oiva_plan_use_graph(oiva_plan *p, int enable);
+/* Two-branch graphs (mode 1; needs use_graph, up to 8 channels, float32 covariance products): the bins in two halves A | B of
+ * whole 64-bin batches, the latency-bound per-bin update (overiva.py:181-190) of one half on a second stream beside the
+ * streaming pass of the other -- act, cov_A, [cov_B || update_A], [power_A || update_B], power_B -- since update(f) needs only
+ * cov(f) and the next power(f) only update(f).  Same kernels on bin ranges: same bits.  0 (default): one stream. */
+int oiva_plan_set_split(oiva_plan *p, int mode);
 /* Arithmetic: an OR of OIVA_PREC_* (default OIVA_PREC_FAST).  Call it before oiva_plan_covariance so that the
  * prologue runs in the same arithmetic. */
 int oiva_plan_set_precision(oiva_plan *p, int flags);

@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "host_io.h"
 #include "oiva_internal.h"
 #include "resident.h"
 
@@ -47,6 +48,7 @@ int round_up(int a, int b) { return (a + b - 1) / b * b; }
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 constexpr int kGraphBatch = 8;       // iterations per captured graph
+constexpr int kSplitGraphBatch = 16; // ... of the two-branch form (the last update of a graph is not overlapped)
 
 }  // namespace
 
@@ -138,11 +140,26 @@ struct oiva_plan {
     unsigned* fx_state = nullptr;               // [0] give-up flag, [16 ...] one epoch counter per workgroup of the activation kernel
     unsigned* fx_flag_host = nullptr;           // pinned: fx_state[0] as copied behind the work on the plan's stream (check_fused)
     int fx_timeout_ms = 0, fx_stall = 0;
+    // hand-over of Y to a host array in slabs of frames (demix_to_host): a second stream for the device-to-host copies, one
+    // event pair per slot of the pinned ring, a device staging ring for complex128 output
+    hipStream_t io_stream = nullptr;
+    hipEvent_t io_written[kHostRingSlots] = {}, io_copied[kHostRingSlots] = {};
+    double2* io_c128[kHostRingSlots] = {};
+    size_t io_c128_bytes = 0;
+    size_t io_slab_bytes = 0;                   // oiva_plan_set_io_slab (0: 8 MB)
     float2* ck_what = nullptr;                  // oiva_plan_save_w: a copy of W_hat (and of its complex128 form) on the device
     double2* ck_what64 = nullptr;
     bool ck_valid = false, ck_what64_valid = false;
     hipGraphExec_t graph_exec = nullptr;        // one iteration
     hipGraphExec_t graph_batch_exec = nullptr;  // kGraphBatch iterations
+    // two-branch graphs (oiva_plan_set_split): the bins in two halves A | B, the per-bin update of a half on a second stream
+    // beside the streaming pass of the other half -- act, cov_A, [cov_B || update_A], [power_A || update_B], power_B
+    int split_mode = 0;
+    int split_fa = 0;                           // bins of half A (whole 64-bin batches)
+    CovGeom split_cov{};                        // frame splits of the half-size covariance launches
+    PowGeom split_pw{};
+    hipStream_t stream2 = nullptr;
+    hipEvent_t sp_ev[4] = {};                   // cov_A done, cov_B done, update_A done, update_B done
     hipEvent_t ev[2] = {};
 };
 
@@ -528,6 +545,100 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     return OIVA_OK;
 }
 
+// ---- two-branch iteration (oiva_plan_set_split) ---------------------------------------------------------
+bool split_applies(const oiva_plan* p) {
+    return p->split_mode && p->use_graph && p->M <= 8 && !p->cov_f64() && !p->cov.pair32 && !(p->prec & OIVA_PREC_UPDATE_ROWS) &&
+           p->pw.nb >= 2 && !p->raw_weights;
+}
+
+// geometry of the half-size launches: what the plan would choose for a shard of half the bins
+int split_setup(oiva_plan* p) {
+    if (!p->stream2) HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+    for (auto& e : p->sp_ev)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const int F = p->F;
+    const CovGeom cov = p->cov;
+    const PowGeom pw = p->pw;
+    p->split_fa = (p->pw.nb / 2) * kBinsPerWave * kWaves;
+    p->F = p->split_fa;
+    choose_cov_geom(p, 0);
+    choose_pow_geom(p, 0);
+    p->split_cov = p->cov;
+    p->split_pw = p->pw;
+    p->F = F;
+    p->cov = cov;
+    p->pw = pw;
+    if (p->split_cov.nsplit > p->vpart_splits_alloc) {
+        const int keep = p->cov.nsplit;
+        p->cov.nsplit = p->split_cov.nsplit;
+        int rc = ensure_vpart(p);
+        p->cov.nsplit = keep;
+        if (rc) return rc;
+    }
+    return OIVA_OK;
+}
+
+int capture_split(oiva_plan* p, int iters, hipGraphExec_t* exec) {
+    const int nbA = p->pw.nb / 2, nbB = p->pw.nb - nbA;
+    const int gA = p->split_fa / kBinsPerWave, gB = p->cov.nbg - gA;
+    PowGeom pwA = p->split_pw, pwB = p->split_pw;
+    pwA.bx0 = 0, pwA.bxn = nbA, pwB.bx0 = nbA, pwB.bxn = nbB;
+    CovGeom cA = p->split_cov, cB = p->split_cov;
+    cA.bx0 = 0, cA.bxn = gA, cB.bx0 = gA, cB.bxn = gB;
+    cA.nbg = cB.nbg = p->cov.nbg;
+    UpdateArgs ua;
+    ua.What = p->What;
+    ua.What64 = p->upd_f64() ? p->What64 : nullptr;
+    ua.Cx = p->Cx;
+    ua.Vpart = p->Vpart;
+    ua.vpart_f64 = p->vpart_f64() ? 1 : 0;
+    ua.wscale = p->wscale;
+    ua.nsplit = p->split_cov.nsplit;
+    ua.T = p->T, ua.F = p->F, ua.M = p->M, ua.K = p->K;
+    ua.init_only = 0;
+    ua.use_double = p->upd_f64() ? 1 : 0;
+    ua.layout = 0;
+    UpdateArgs uA = ua, uB = ua;
+    uA.f0 = 0, uA.f1 = p->split_fa, uB.f0 = p->split_fa, uB.f1 = p->F;
+    hipEvent_t evA = p->sp_ev[0], evB = p->sp_ev[1], evUA = p->sp_ev[2], evUB = p->sp_ev[3];
+    const float2* xpad = nullptr;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipSuccess;
+    int rc = OIVA_OK;
+    for (int i = 0; i < iters && e == hipSuccess && rc == OIVA_OK; ++i) {
+        if (i > 0) e = hipStreamWaitEvent(p->stream, evUA, 0);
+        if (e == hipSuccess) e = launch_power(p->stream, p->X, xpad, p->What, p->Ppart, p->T, p->F, p->M, p->K, pwA);
+        if (e == hipSuccess && i > 0) e = hipStreamWaitEvent(p->stream, evUB, 0);
+        if (e == hipSuccess) e = launch_power(p->stream, p->X, xpad, p->What, p->Ppart, p->T, p->F, p->M, p->K, pwB);
+        if (e == hipSuccess) rc = stage_activation(p, p->Ppart, p->pw.nb);
+        if (rc) break;
+        e = launch_cov(p->stream, p->X, nullptr, p->R, p->Plocal, p->wscale, p->model, 0, p->Vpart, false, p->T, p->F, p->M, p->K, cA);
+        if (e == hipSuccess) e = hipEventRecord(evA, p->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p->stream2, evA, 0);
+        if (e == hipSuccess) e = launch_update(p->stream2, uA);
+        if (e == hipSuccess) e = hipEventRecord(evUA, p->stream2);
+        if (e == hipSuccess) e = launch_cov(p->stream, p->X, nullptr, p->R, p->Plocal, p->wscale, p->model, 0, p->Vpart, false, p->T, p->F, p->M, p->K, cB);
+        if (e == hipSuccess) e = hipEventRecord(evB, p->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p->stream2, evB, 0);
+        if (e == hipSuccess) e = launch_update(p->stream2, uB);
+        if (e == hipSuccess) e = hipEventRecord(evUB, p->stream2);
+    }
+    if (e == hipSuccess && rc == OIVA_OK) e = hipStreamWaitEvent(p->stream, evUB, 0);      // join
+    hipError_t ec = hipStreamEndCapture(p->stream, &graph);
+    if (rc || e != hipSuccess || ec != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        if (rc) return rc;
+        HIP_TRY(e);
+        HIP_TRY(ec);
+    }
+    e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HIP_TRY(e);
+    HIP_TRY(hipGraphUpload(*exec, p->stream));
+    return OIVA_OK;
+}
+
 // Capture (stream capture records, it does not execute) and instantiate the two graphs an iterate() call
 // replays: kGraphBatch iterations (amortises the ~10-16 us replay floor, which matters when an iteration is tens
 // of microseconds) and a single iteration for the remainder.  Called from oiva_plan_use_graph when the plan
@@ -555,6 +666,14 @@ int build_graphs(oiva_plan* p) {
     const bool pending = p->wscale_pending;
     const int raw = p->raw_weights;
     int rc = OIVA_OK;
+    if (split_applies(p)) {
+        if (!p->graph_batch_exec || !p->graph_exec) rc = split_setup(p);
+        if (!rc && !p->graph_batch_exec) rc = capture_split(p, kSplitGraphBatch, &p->graph_batch_exec);
+        if (!rc && !p->graph_exec) rc = capture_split(p, 1, &p->graph_exec);
+        p->wscale_pending = pending;
+        p->raw_weights = raw;
+        return rc;
+    }
     if (!p->graph_batch_exec) rc = capture(kGraphBatch, &p->graph_batch_exec);
     if (!rc && !p->graph_exec) rc = capture(1, &p->graph_exec);
     p->wscale_pending = pending;   // capturing toggled the host-side flags without running anything
@@ -736,6 +855,15 @@ int oiva_plan_destroy(oiva_plan* p) {
     if (p->fx_loop_buf) (void)hipFree(p->fx_loop_buf);
     if (p->fx_state) (void)hipFree(p->fx_state);
     if (p->fx_flag_host) (void)hipHostFree(p->fx_flag_host);
+    if (p->io_stream) (void)hipStreamDestroy(p->io_stream);
+    if (p->stream2) (void)hipStreamDestroy(p->stream2);
+    for (auto& e : p->sp_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < kHostRingSlots; ++i) {
+        if (p->io_written[i]) (void)hipEventDestroy(p->io_written[i]);
+        if (p->io_copied[i]) (void)hipEventDestroy(p->io_copied[i]);
+        if (p->io_c128[i]) (void)hipFree(p->io_c128[i]);
+    }
     if (p->ck_what) (void)hipFree(p->ck_what);
     if (p->ck_what64) (void)hipFree(p->ck_what64);
     for (auto& ev : p->ev)
@@ -934,7 +1062,8 @@ int oiva_plan_iterate(oiva_plan* p, int n) {
     if (p->use_graph) {
         if ((rc = build_graphs(p))) return rc;
         int left = n;
-        for (; left >= kGraphBatch; left -= kGraphBatch) HIP_TRY(hipGraphLaunch(p->graph_batch_exec, p->stream));
+        const int batch = split_applies(p) ? kSplitGraphBatch : kGraphBatch;
+        for (; left >= batch; left -= batch) HIP_TRY(hipGraphLaunch(p->graph_batch_exec, p->stream));
         for (; left > 0; --left) HIP_TRY(hipGraphLaunch(p->graph_exec, p->stream));
         p->wscale_pending = false;
         return OIVA_OK;
@@ -982,52 +1111,141 @@ int oiva_plan_update(oiva_plan* p, const void* parts_dev, int nparts) {
     return stage_update(p, false);
 }
 
-int oiva_plan_demix(oiva_plan* p, void* Y_host, long long row_pitch_bytes, int proj_back) {
-    int rc = check_ready(p);
-    if (rc) return rc;
-    NEED(Y_host, OIVA_ERR_ARG, "null output");
-    DeviceGuard guard(p->device);
-    const size_t row = (size_t)p->F * p->K * sizeof(float2);
-    const size_t pitch = row_pitch_bytes > 0 ? (size_t)row_pitch_bytes : row;
-    NEED(pitch >= row, OIVA_ERR_ARG, "row pitch smaller than one frame of this plan's bins");
-    if ((rc = check_fused(p))) return rc;
-    if (!p->Y) HIP_TRY(hipMalloc(&p->Y, row * p->T));
-    const float* sp = nullptr;
-    if (proj_back) {
-        HIP_TRY(launch_demix_stats(p->stream, p->X, p->What, p->Spart, p->T, p->F, p->M, p->K, p->stg));
-        sp = p->Spart;
-    }
-    HIP_TRY(launch_demix_write(p->stream, p->X, p->What, sp, p->stg.nsplit, p->Y, p->T, p->F, p->M, p->K));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy2D(Y_host, pitch, p->Y, row, row, p->T, hipMemcpyDeviceToHost));
-    return OIVA_OK;
-}
-
-int oiva_plan_demix_c128(oiva_plan* p, void* Y_host, long long row_pitch_bytes, int proj_back) {
+// Y = demix(X, W) (+ projection back) into a host array, complex64 or complex128 (overiva.py:192-204).
+//   $OIVA_DEMIX_IO = ring (default): slabs of frames; slab k is computed (write_kernel; for complex128 also widened on the
+//       device), copied into a slot of the process-wide pinned ring on a second stream and moved from there into the
+//       caller's array by the copy threads, all three overlapping across slabs;
+//   register: the caller's array is page-locked for the call (hipHostRegister) and the slabs are copied straight into it;
+//   legacy: one kernel over all frames, one synchronous hipMemcpy2D (the form up to round 4).
+// Same bits in every mode: the kernel does the same arithmetic per (frame, bin) whatever the slab.
+static int demix_to_host(oiva_plan* p, void* Y_host, long long row_pitch_bytes, int proj_back, bool c128) {
     int rc = check_ready(p);
     if (rc) return rc;
     NEED(Y_host, OIVA_ERR_ARG, "null output");
     DeviceGuard guard(p->device);
     const size_t n_row = (size_t)p->F * p->K;
-    const size_t row = n_row * sizeof(double2);
+    const size_t row_dev = n_row * sizeof(float2);
+    const size_t row = c128 ? n_row * sizeof(double2) : row_dev;
     const size_t pitch = row_pitch_bytes > 0 ? (size_t)row_pitch_bytes : row;
     NEED(pitch >= row, OIVA_ERR_ARG, "row pitch smaller than one frame of this plan's bins");
-    void* ydev = nullptr;
-    if ((rc = oiva_plan_demix_dev(p, proj_back, &ydev))) return rc;
-    const int slab = (int)std::max<size_t>(1, std::min<size_t>((size_t)p->T, ((size_t)256 << 20) / row));
-    double2* stage = nullptr;
-    HIP_TRY(hipMalloc(&stage, row * slab));
-    hipError_t e = hipSuccess;
-    for (int t0 = 0; t0 < p->T && e == hipSuccess; t0 += slab) {
-        const int nt = std::min(slab, p->T - t0);
-        e = launch_cast_c64_to_c128(p->stream, static_cast<const float2*>(ydev) + (size_t)t0 * n_row, stage, (long long)nt * n_row);
-        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-        if (e == hipSuccess)
-            e = hipMemcpy2D(static_cast<char*>(Y_host) + (size_t)t0 * pitch, pitch, stage, row, row, nt, hipMemcpyDeviceToHost);
+    if ((rc = check_fused(p))) return rc;
+    if (!p->Y) HIP_TRY(hipMalloc(&p->Y, row_dev * p->T));
+    const float* sp = nullptr;
+    if (proj_back) {
+        HIP_TRY(launch_demix_stats(p->stream, p->X, p->What, p->Spart, p->T, p->F, p->M, p->K, p->stg));
+        sp = p->Spart;
     }
-    (void)hipFree(stage);
-    HIP_TRY(e);
+    static const int mode = [] {
+        const char* v = std::getenv("OIVA_DEMIX_IO");
+        if (v && !std::strcmp(v, "legacy")) return 0;
+        if (v && !std::strcmp(v, "register")) return 2;
+        return 1;
+    }();
+    const size_t slab_target = p->io_slab_bytes ? p->io_slab_bytes : ((size_t)8 << 20);
+    if (mode == 0 || (size_t)p->T * row < slab_target / 2) {
+        // small outputs (and the legacy form): one kernel, one copy
+        HIP_TRY(launch_demix_write(p->stream, p->X, p->What, sp, p->stg.nsplit, p->Y, p->T, p->F, p->M, p->K));
+        if (!c128) {
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            HIP_TRY(hipMemcpy2D(Y_host, pitch, p->Y, row, row, p->T, hipMemcpyDeviceToHost));
+            return OIVA_OK;
+        }
+        const int slab = (int)std::max<size_t>(1, std::min<size_t>((size_t)p->T, ((size_t)256 << 20) / row));
+        double2* stage = nullptr;
+        HIP_TRY(hipMalloc(&stage, row * slab));
+        hipError_t e = hipSuccess;
+        for (int t0 = 0; t0 < p->T && e == hipSuccess; t0 += slab) {
+            const int nt = std::min(slab, p->T - t0);
+            e = launch_cast_c64_to_c128(p->stream, p->Y + (size_t)t0 * n_row, stage, (long long)nt * n_row);
+            if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+            if (e == hipSuccess)
+                e = hipMemcpy2D(static_cast<char*>(Y_host) + (size_t)t0 * pitch, pitch, stage, row, row, nt, hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(stage);
+        HIP_TRY(e);
+        return OIVA_OK;
+    }
+    // ---- slabs of about 8 MB of output
+    const int slab = (int)std::max<size_t>(1, std::min<size_t>((size_t)p->T, slab_target / row));
+    const int nslab = ceil_div(p->T, slab);
+    const size_t slab_bytes = (size_t)slab * row;
+    if (!p->io_stream) HIP_TRY(hipStreamCreateWithFlags(&p->io_stream, hipStreamNonBlocking));
+    for (int i = 0; i < kHostRingSlots; ++i) {
+        if (!p->io_written[i]) HIP_TRY(hipEventCreateWithFlags(&p->io_written[i], hipEventDisableTiming));
+        if (!p->io_copied[i]) HIP_TRY(hipEventCreateWithFlags(&p->io_copied[i], hipEventDisableTiming));
+    }
+    if (c128 && p->io_c128_bytes < slab_bytes) {
+        for (auto& b : p->io_c128) {
+            if (b) HIP_TRY(hipFree(b));
+            b = nullptr;
+            HIP_TRY(hipMalloc((void**)&b, slab_bytes));
+        }
+        p->io_c128_bytes = slab_bytes;
+    }
+    bool registered = false;
+    void* pinned[kHostRingSlots] = {};
+    if (mode == 2) {
+        registered = hipHostRegister(Y_host, pitch * (size_t)(p->T - 1) + row, hipHostRegisterDefault) == hipSuccess;
+        if (!registered) (void)hipGetLastError();      // (an unaligned or foreign range: the ring serves)
+    }
+    if (!registered) HIP_TRY(host_ring_slots(slab_bytes, pinned));
+    auto finish = [&](hipError_t e) -> int {
+        if (registered) {
+            (void)hipStreamSynchronize(p->io_stream);
+            (void)hipHostUnregister(Y_host);
+        }
+        if (e != hipSuccess) return fail(OIVA_ERR_HIP, std::string("final demix: ") + hipGetErrorString(e));
+        return OIVA_OK;
+    };
+    auto issue = [&](int k) -> hipError_t {
+        const int s = k % kHostRingSlots;
+        const int t0 = k * slab, nt = std::min(slab, p->T - t0);
+        float2* ydev = p->Y + (size_t)t0 * n_row;
+        hipError_t e = launch_demix_write(p->stream, p->X + (size_t)t0 * p->F * p->M, p->What, sp, p->stg.nsplit, ydev, nt, p->F, p->M, p->K);
+        const void* src = ydev;
+        if (e == hipSuccess && c128) {
+            e = launch_cast_c64_to_c128(p->stream, ydev, p->io_c128[s], (long long)nt * n_row);
+            src = p->io_c128[s];
+        }
+        if (e == hipSuccess) e = hipEventRecord(p->io_written[s], p->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p->io_stream, p->io_written[s], 0);
+        if (e == hipSuccess) {
+            if (registered)
+                e = hipMemcpy2DAsync(static_cast<char*>(Y_host) + (size_t)t0 * pitch, pitch, src, row, row, nt, hipMemcpyDeviceToHost, p->io_stream);
+            else
+                e = hipMemcpyAsync(pinned[s], src, (size_t)nt * row, hipMemcpyDeviceToHost, p->io_stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(p->io_copied[s], p->io_stream);
+        // (slot s -- the pinned buffer and, for complex128, the device staging buffer -- is rewritten by slab k + slots, which
+        //  the loop below issues only after it has waited for THIS copy and moved its data on)
+        return e;
+    };
+    int issued = 0;
+    for (int k = 0; k < nslab; ++k) {
+        hipError_t e = hipSuccess;
+        while (issued < nslab && issued - k < kHostRingSlots && e == hipSuccess) e = issue(issued++);
+        if (e == hipSuccess) e = hipEventSynchronize(p->io_copied[k % kHostRingSlots]);
+        if (e != hipSuccess) return finish(e);
+        if (!registered) {
+            const int t0 = k * slab, nt = std::min(slab, p->T - t0);
+            host_copy_rows(static_cast<char*>(Y_host) + (size_t)t0 * pitch, pitch, pinned[k % kHostRingSlots], row, row, nt);
+        }
+    }
+    return finish(hipStreamSynchronize(p->stream));
+}
+
+int oiva_plan_set_io_slab(oiva_plan* p, long long bytes) {
+    NEED(p && bytes >= 0, OIVA_ERR_ARG, "bad arguments");
+    p->io_slab_bytes = (size_t)bytes;
     return OIVA_OK;
+}
+
+int oiva_plan_demix(oiva_plan* p, void* Y_host, long long row_pitch_bytes, int proj_back) {
+    return demix_to_host(p, Y_host, row_pitch_bytes, proj_back, false);
+}
+
+int oiva_plan_demix_c128(oiva_plan* p, void* Y_host, long long row_pitch_bytes, int proj_back) {
+    return demix_to_host(p, Y_host, row_pitch_bytes, proj_back, true);
 }
 
 int oiva_plan_get_w(oiva_plan* p, void* W_host, int f64) {
@@ -1328,6 +1546,16 @@ int oiva_plan_set_pow_splits(oiva_plan* p, int nsplit) {
     int rc = drop_graph(p);
     if (rc) return rc;
     choose_pow_geom(p, nsplit);
+    return OIVA_OK;
+}
+
+int oiva_plan_set_split(oiva_plan* p, int mode) {
+    NEED(p && (mode == 0 || mode == 1), OIVA_ERR_ARG, "bad arguments");
+    DeviceGuard guard(p->device);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    int rc = drop_graph(p);
+    if (rc) return rc;
+    p->split_mode = mode;
     return OIVA_OK;
 }
 

@@ -165,6 +165,15 @@ def overiva(
                                           exchange=group[1] if len(group) > 1 else None)
     else:
         solver = _SingleDevice(n_frames, n_freq, n_chan, n_src, model, precision)
+    # the array the call returns, allocated now and its pages faulted in by the library's copy threads WHILE X is uploaded and
+    # the iterations run: the final hand-over (131 MB at the headline shape) then meets resident pages (csrc/host_io.hip)
+    out, prefault = None, None
+    if group is None and n_frames * n_freq * n_src * np.dtype(dtype).itemsize >= _PREFAULT_MIN_BYTES:
+        import threading
+
+        out = np.empty((n_frames, n_freq, n_src), dtype)
+        prefault = threading.Thread(target=_prefault, args=(out,), daemon=True)
+        prefault.start()
     try:
         solver.set_x(X)
         solver.covariance()
@@ -184,7 +193,11 @@ def overiva(
             solver.iterate(step)
             epoch += step
 
-        Y = solver.demix(proj_back, dtype)
+        if prefault is not None:
+            prefault.join()
+            Y = solver.demix(proj_back, dtype, out=out)
+        else:
+            Y = solver.demix(proj_back, dtype)
         if return_filters:
             return Y, solver.get_w().astype(dtype, copy=False)
         # surface a singular solve the way numpy.linalg.solve would (overiva.py:182)
@@ -192,6 +205,21 @@ def overiva(
         return Y
     finally:
         solver.close()
+
+
+_PREFAULT_MIN_BYTES = 4 << 20
+
+
+def _prefault(a):
+    """fault the pages of a freshly allocated array in (ctypes releases the GIL for the call)"""
+    import ctypes as C
+
+    from . import _lib
+
+    try:
+        _lib.load().oiva_host_prefault(C.c_void_p(a.ctypes.data), a.nbytes)
+    except Exception:      # (an optimisation only)
+        pass
 
 
 # (device, T, F, M, K) whose X-resident launch gave up in this process (its workgroups were not all co-resident: a shared or
@@ -239,8 +267,8 @@ class _SingleDevice:
     def iterate(self, n):
         self.plan.iterate(n)
 
-    def demix(self, proj_back, dtype=np.complex64):
-        return self.plan.demix(proj_back, dtype=dtype)
+    def demix(self, proj_back, dtype=np.complex64, out=None):
+        return self.plan.demix(proj_back, dtype=dtype, out=out)
 
     def get_w(self):
         return self.plan.get_w(self.wdtype)

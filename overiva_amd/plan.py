@@ -184,6 +184,10 @@ class Plan:
         _lib.check(fn(self.h, C.c_void_p(base), pitch, 1 if proj_back else 0))
         return out
 
+    def set_io_slab(self, nbytes=0):
+        """bytes of output per slab of the pipelined hand-over of ``demix`` (0: the default); test hook"""
+        _lib.check(self.lib.oiva_plan_set_io_slab(self.h, int(nbytes)))
+
     def demix_device(self, proj_back=False):
         """Y stays on the device: a ``DeviceX`` (T, F, K) that another plan can take as its input (``set_x``); valid
         until this plan's next demix or its close()."""
@@ -233,6 +237,11 @@ class Plan:
 
     def use_graph(self, enable=True):
         _lib.check(self.lib.oiva_plan_use_graph(self.h, 1 if enable else 0))
+
+    def set_split(self, mode=1):
+        """two-branch graphs: the per-bin update of one half of the bins beside the streaming pass of the other half (see
+        ``oiva_plan_set_split``); needs ``use_graph``"""
+        _lib.check(self.lib.oiva_plan_set_split(self.h, int(mode)))
 
     def set_precision(self, mode="fast", row_layout=False):
         """``"fast"`` (float32 products, lane chains and per-bin algebra), ``"mixed"`` (float32 products and lane

@@ -1,0 +1,82 @@
+"""The hand-over of Y to the caller's host array (reference overiva.py:192-204), csrc/plan.hip::demix_to_host + csrc/host_io.hip:
+slabs of frames through the pinned ring and the copy threads, the page-locked destination, the one-copy form -- same bits in
+every form, for complex64 and complex128 output, dense and pitched destinations, with and without projection back."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import overiva_oracle as orc
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import overiva_amd
+    from overiva_amd import _lib
+
+    _lib.load()
+    return overiva_amd
+
+
+@pytest.mark.parametrize("shape", [(130, 21, 4, 2), (257, 40, 8, 3), (64, 7, 16, 16), (1000, 64, 2, 1)])
+def test_slabs_give_the_bits_of_one_copy(oa, shape):
+    T, F, M, K = shape
+    X = orc.synth_mixture(T, F, M, K, seed=4)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision("mixed")
+        p.set_x(X)
+        p.covariance()
+        p.set_w(None)
+        p.iterate(2)
+        ref = {(pb, dt): p.demix(pb, dtype=dt) for pb in (False, True) for dt in (np.complex64, np.complex128)}      # small: one copy
+        for slab in (1, 5000, 64 << 10):            # one frame per slab ... a few slabs
+            p.set_io_slab(slab)
+            for (pb, dt), want in ref.items():
+                got = p.demix(pb, dtype=dt)
+                assert got.dtype == dt and np.array_equal(got, want), (slab, pb, dt)
+            # a pitched destination: bins 3 .. 3 + F of a wider array, the rest untouched
+            out = np.full((T, F + 9, K), 7 + 7j, np.complex128)
+            p.demix(True, out=out, f0=3)
+            assert np.array_equal(out[:, 3:3 + F], ref[(True, np.complex128)])
+            assert np.all(out[:, :3] == 7 + 7j) and np.all(out[:, 3 + F:] == 7 + 7j)
+        p.set_io_slab(0)
+        assert np.array_equal(p.demix(True), ref[(True, np.complex64)])
+
+
+def test_prefault_keeps_the_contents(oa):
+    import ctypes as C
+
+    from overiva_amd import _lib
+
+    a = np.arange(3_000_001, dtype=np.float64)[1:]         # not page aligned
+    keep = a.copy()
+    _lib.check(_lib.load().oiva_host_prefault(C.c_void_p(a.ctypes.data), a.nbytes))
+    assert np.array_equal(a, keep)
+
+
+@pytest.mark.parametrize("mode", ["legacy", "ring", "register"])
+def test_every_form_of_the_hand_over_in_the_drop_in_call(mode, tmp_path):
+    """overiva() end to end in a process of its own with $OIVA_DEMIX_IO set (read once per process): 8 MB of complex64 and
+    16 MB of complex128 output, against the legacy form's bits"""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import overiva_amd as oa\n"
+        "from oracle import overiva_oracle as orc\n"
+        "X = orc.synth_mixture(1000, 513, 4, 2, seed=1)\n"
+        "Y64, W = oa.overiva(X, n_src=2, n_iter=3, return_filters=True)\n"
+        "Y128 = oa.overiva(X.astype(np.complex128), n_src=2, n_iter=3)\n"
+        "np.savez(%r, Y64=Y64, Y128=Y128, W=W)\n") % (REPO, str(tmp_path / f"{mode}.npz"))
+    outs = {}
+    for m in ("legacy", mode):
+        code_m = code.replace(f"{mode}.npz", f"{m}.npz")
+        r = subprocess.run([sys.executable, "-c", code_m], env=dict(os.environ, OIVA_DEMIX_IO=m), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[m] = np.load(tmp_path / f"{m}.npz")
+    for k in ("Y64", "Y128", "W"):
+        assert np.array_equal(outs[mode][k], outs["legacy"][k]), k
+    assert outs[mode]["Y128"].dtype == np.complex128
