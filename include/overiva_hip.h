@@ -138,6 +138,9 @@ int oiva_plan_update(oiva_plan *p, const void *parts_dev, int nparts);
  * allocation: oiva_host_prefault does that, from the pool's threads, e.g. while the iterations run.
  */
 int oiva_plan_demix(oiva_plan *p, void *Y_host, long long row_pitch_bytes, int proj_back);
+/* Device buffers of >= 16 MB that a destroyed plan owned (its copy of X, Y, staging) stay in a process-wide pool for the next
+ * plan of the same shape -- at most $OIVA_POOL_MB (default 2048; 0: nothing is kept).  This releases them to the driver. */
+int oiva_pool_trim(void);
 /* Bytes of output per slab of the hand-over above (0: the default, 8 MB).  Test hook. */
 int oiva_plan_set_io_slab(oiva_plan *p, long long bytes);
 /* Fault the pages of [ptr, ptr + bytes) in for writing, contents unchanged, using the library's copy threads.  Blocking;
@@ -231,11 +234,6 @@ int oiva_plan_set_pow_splits(oiva_plan *p, int nsplit);
 int oiva_plan_set_cov_hmfma(oiva_plan *p, int enable);
 /* Replay the iteration from a captured hipGraph instead of eager launches (default off). */
 int oiva_plan_use_graph(oiva_plan *p, int enable);
-/* Two-branch graphs (mode 1; needs use_graph, up to 8 channels, float32 covariance products): the bins in two halves A | B of
- * whole 64-bin batches, the latency-bound per-bin update (overiva.py:181-190) of one half on a second stream beside the
- * streaming pass of the other -- act, cov_A, [cov_B || update_A], [power_A || update_B], power_B -- since update(f) needs only
- * cov(f) and the next power(f) only update(f).  Same kernels on bin ranges: same bits.  0 (default): one stream. */
-int oiva_plan_set_split(oiva_plan *p, int mode);
 /* Arithmetic: an OR of OIVA_PREC_* (default OIVA_PREC_FAST).  Call it before oiva_plan_covariance so that the
  * prologue runs in the same arithmetic. */
 int oiva_plan_set_precision(oiva_plan *p, int flags);

@@ -16,9 +16,10 @@ _lib_mod._set_ipc_env_at_import()
 from ._lib import HipError, HipLibraryMissing  # noqa: E402,F401
 from .auxiva_pca import auxiva_pca  # noqa: F401
 from .ive import ogive  # noqa: F401
-from .overiva import get_device, get_precision, last_solver_info, overiva, set_device, set_precision  # noqa: F401
+from .overiva import (get_device, get_precision, last_solver_info, overiva, release_cached_buffers, set_device,  # noqa: F401
+                      set_precision)
 from .plan import DeviceX, Plan  # noqa: F401
 from .sharded import BinShardedSolver, disable_bin_sharding, enable_bin_sharding, shard_bounds  # noqa: F401
 
 __all__ = ["overiva", "auxiva_pca", "ogive", "Plan", "DeviceX", "BinShardedSolver", "enable_bin_sharding", "disable_bin_sharding",
-           "shard_bounds", "set_device", "get_device", "set_precision", "get_precision", "last_solver_info", "HipError", "HipLibraryMissing"]
+           "shard_bounds", "release_cached_buffers", "set_device", "get_device", "set_precision", "get_precision", "last_solver_info", "HipError", "HipLibraryMissing"]

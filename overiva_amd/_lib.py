@@ -55,6 +55,7 @@ SIGNATURES = {
     "oiva_plan_demix_dev": [_vp, _i, _vp],
     "oiva_plan_set_io_slab": [_vp, _ll],
     "oiva_host_prefault": [_vp, _ll],
+    "oiva_pool_trim": [],
     "oiva_plan_demix_c128": [_vp, _vp, _ll, _i],
     "oiva_plan_set_w_pca": [_vp, _vp],
     "oiva_plan_set_w_eig": [_vp],
@@ -78,7 +79,6 @@ SIGNATURES = {
     "oiva_plan_set_pow_splits": [_vp, _i],
     "oiva_plan_set_cov_hmfma": [_vp, _i],
     "oiva_plan_use_graph": [_vp, _i],
-    "oiva_plan_set_split": [_vp, _i],
     "oiva_plan_set_precision": [_vp, _i],
     "oiva_plan_set_resident": [_vp, _i],
     "oiva_plan_resident_info": [_vp, C.POINTER(_i)],

@@ -146,6 +146,16 @@ void host_prefault(void* ptr, size_t bytes) {
     if (!ptr || bytes == 0) return;
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
     CopyPool& p = pool();
+#ifdef MADV_HUGEPAGE
+    {
+        // $OIVA_IO_THP=1: ask for 2 MB pages where the system gives them on request (transparent huge pages in `madvise`
+        // mode).  Off by default: measured on the MI355X box (EPYC 9575F) the pre-fault of 131 MB took 1.9-2.5 ms with the
+        // advice against 1.1 ms without, and the hand-over that follows was no faster.
+        static const bool thp = [] { const char* v = std::getenv("OIVA_IO_THP"); return v && v[0] == '1'; }();
+        const uintptr_t a2 = ((uintptr_t)ptr + page - 1) & ~(uintptr_t)(page - 1), b2 = ((uintptr_t)ptr + bytes) & ~(uintptr_t)(page - 1);
+        if (thp && b2 > a2 && b2 - a2 >= ((size_t)4 << 20)) (void)madvise((void*)a2, b2 - a2, MADV_HUGEPAGE);
+    }
+#endif
     p.run([&](int j, int n) {
         // whole pages of this thread's share of the range (the first and last partial pages are touched by their owners too)
         const uintptr_t a = (uintptr_t)ptr, b = a + bytes;

@@ -31,12 +31,12 @@ constexpr int kLdsStride = kBlock + 1;   // +1: conflict-free transposed read
 // covers T / (16 nsplit) frames, and adding 16 (then nsplit) of them in float32 would cost as much accuracy again as
 // the chains themselves (measured on the reference's fixtures: 1.5-4 of its complex64 floors -> below one).
 template <int M, int KC, typename ACC, typename At>
-__device__ __forceinline__ void reduce_and_store_at(At&& at, ACC* lds, double* __restrict__ Vpart, int F, int K, int k0, int bx) {
+__device__ __forceinline__ void reduce_and_store_at(At&& at, ACC* lds, double* __restrict__ Vpart, int F, int K, int k0) {
     constexpr int NA = M * M;
     constexpr int NACC = NA * KC;
     const int tid = threadIdx.x;
     const int bb = tid >> 4, aa = tid & 15;
-    const int fo = bx * kBinsPerWave + bb;
+    const int fo = blockIdx.x * kBinsPerWave + bb;
     double* out = Vpart + (((size_t)blockIdx.y * F + fo) * K + k0) * NA;
 #pragma unroll
     for (int r0 = 0; r0 < NACC; r0 += kChunk) {
@@ -57,24 +57,23 @@ __device__ __forceinline__ void reduce_and_store_at(At&& at, ACC* lds, double* _
 
 template <int M, int KC, typename ACC>
 __device__ __forceinline__ void reduce_and_store(const ACC (&acc)[KC][M * M], ACC* lds, double* __restrict__ Vpart,
-                                                 int F, int K, int k0, int bx) {
-    reduce_and_store_at<M, KC, ACC>([&](int e) { return acc[e / (M * M)][e % (M * M)]; }, lds, Vpart, F, K, k0, bx);
+                                                 int F, int K, int k0) {
+    reduce_and_store_at<M, KC, ACC>([&](int e) { return acc[e / (M * M)][e % (M * M)]; }, lds, Vpart, F, K, k0);
 }
 
 template <int M, int KC, bool UNIT, typename ACC>
 __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ X, const float* __restrict__ R,
                                                      float* __restrict__ wscale, int model, int raw,
-                                                     double* __restrict__ Vpart, int T, int F, int K, int tc, int bx0) {
+                                                     double* __restrict__ Vpart, int T, int F, int K, int tc) {
     constexpr int NA = M * M;
     __shared__ ACC lds[kChunk * kLdsStride];
-    const int bx = blockIdx.x + bx0;            // bin group (a launch may cover a range of them)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int b = lane & (kBinsPerWave - 1);
     const int q = wave * kPhasesPerWave + (lane >> 4);  // 0..15, == tid >> 4
-    const int f = bx * kBinsPerWave + b;
+    const int f = blockIdx.x * kBinsPerWave + b;
     const int fc = f < F ? f : F - 1;
     const int k0 = blockIdx.z * KC;
     const int t_begin = blockIdx.y * tc;
@@ -149,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void cov_kernel(const float2* __restrict__ 
         }
     }
 
-    reduce_and_store<M, KC, ACC>(acc, lds, Vpart, F, K, k0, bx);
+    reduce_and_store<M, KC, ACC>(acc, lds, Vpart, F, K, k0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -199,10 +198,9 @@ __device__ __forceinline__ void ring_read<2>(unsigned addr, float4 (&v)[2]) {
 template <int M, int KC>
 __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __restrict__ X, const float* __restrict__ R,
                                                             float* __restrict__ wscale, int model, int raw,
-                                                            double* __restrict__ Vpart, int T, int F, int K, int tc, int bx0) {
+                                                            double* __restrict__ Vpart, int T, int F, int K, int tc) {
     constexpr int NA = M * M;
     constexpr int PIECES = M / 2;                       // 16-byte pieces of one M-vector
-    const int bx = blockIdx.x + bx0;                    // bin group (a launch may cover a range of them)
     constexpr int STAGE = PIECES * 64;                  // float4 per stage per wave
     static_assert(M % 2 == 0 && (PIECES == 2 || PIECES == 4), "LDS-DMA path: M in {4, 8}");
     __shared__ float4 ring[kWaves * kDmaStages * STAGE];
@@ -215,7 +213,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
     const int b = lane & (kBinsPerWave - 1);
     const int ql = lane >> 4;                           // phase inside the wave
     const int q = wave * kPhasesPerWave + ql;           // 0..15
-    const int f = bx * kBinsPerWave + b;
+    const int f = blockIdx.x * kBinsPerWave + b;
     const int fc = f < F ? f : F - 1;
     const int k0 = blockIdx.z * KC;
     const int t_begin = blockIdx.y * tc;
@@ -321,13 +319,13 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
     // (adding the 4 phases of a wave in registers first -- v_permlane16/32_swap, a quarter of the LDS traffic, 4
     // barriers instead of 16 -- was measured slower: 102-104 us against 96-98)
     if constexpr (kPacked)
-        reduce_and_store_at<M, KC, float>([&](int e) { return pacc.at(e); }, reinterpret_cast<float*>(ring), Vpart, F, K, k0, bx);
+        reduce_and_store_at<M, KC, float>([&](int e) { return pacc.at(e); }, reinterpret_cast<float*>(ring), Vpart, F, K, k0);
     else
-        reduce_and_store<M, KC, float>(acc, reinterpret_cast<float*>(ring), Vpart, F, K, k0, bx);
+        reduce_and_store<M, KC, float>(acc, reinterpret_cast<float*>(ring), Vpart, F, K, k0);
 }
 
 template <typename ACC>
-using CovKernel = void (*)(const float2*, const float*, float*, int, int, double*, int, int, int, int, int);   // ACC = accumulator type
+using CovKernel = void (*)(const float2*, const float*, float*, int, int, double*, int, int, int, int);   // ACC = accumulator type
 
 // (M, KC, unit weights) -> kernel instantiation, handed to fn together with its KC.  Register budget:
 // KC * M^2 accumulators of ACC must stay below ~144 registers.
@@ -421,13 +419,13 @@ hipError_t launch_cov(hipStream_t s, const float2* X, const float2* Xpad, const 
     const int kc = R == nullptr ? 1 : g.kc;
     if (f64)
         return dispatch_cov<double>(M, kc, R == nullptr, [&](CovKernel<double> kern, int KC) {
-            kern<<<dim3(g.bxn ? g.bxn : g.nbg, g.nsplit, (K + KC - 1) / KC), dim3(kBlock), 0, s>>>(X, R, wscale, model, raw,
-                                                                                 static_cast<double*>(Vpart), T, F, K, g.tc, g.bx0);
+            kern<<<dim3(g.nbg, g.nsplit, (K + KC - 1) / KC), dim3(kBlock), 0, s>>>(X, R, wscale, model, raw,
+                                                                                 static_cast<double*>(Vpart), T, F, K, g.tc);
             return hipGetLastError();
         });
     return dispatch_cov<float>(M, kc, R == nullptr, [&](CovKernel<float> kern, int KC) {
-        return launch_dominant(kern, dim3(g.bxn ? g.bxn : g.nbg, g.nsplit, (K + KC - 1) / KC), dim3(kBlock), 0, s, X, R, wscale, model, raw,
-                               static_cast<double*>(Vpart), T, F, K, g.tc, g.bx0);
+        return launch_dominant(kern, dim3(g.nbg, g.nsplit, (K + KC - 1) / KC), dim3(kBlock), 0, s, X, R, wscale, model, raw,
+                               static_cast<double*>(Vpart), T, F, K, g.tc);
     });
 }
 

@@ -17,15 +17,14 @@ constexpr int kPowUnroll = 2;
 
 template <int M, int KP>
 __global__ __launch_bounds__(kBlock) void power_kernel(const float2* __restrict__ X, const float2* __restrict__ What,
-                                                       float* __restrict__ Ppart, int T, int F, int K, int tcp, int bx0) {
+                                                       float* __restrict__ Ppart, int T, int F, int K, int tcp) {
     extern __shared__ __attribute__((aligned(16))) float sp[];  // [kWaves][tcp][KP]
-    const int bx = blockIdx.x + bx0;            // 64-bin batch (a launch may cover a range of them)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int b = lane & 15;
     const int q = lane >> 4;
-    const int f = (bx * kWaves + wave) * kBinsPerWave + b;
+    const int f = (blockIdx.x * kWaves + wave) * kBinsPerWave + b;
     const bool fvalid = f < F;
     const int fc = fvalid ? f : F - 1;
     const int k0 = blockIdx.z * KP;
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void power_kernel(const float2* __restrict_
         float s = sp[(0 * tcp + tl) * KP + kk];
 #pragma unroll
         for (int w = 1; w < kWaves; ++w) s += sp[(w * tcp + tl) * KP + kk];
-        if (k0 + kk < K) Ppart[((size_t)bx * T + t_begin + tl) * K + k0 + kk] = s;
+        if (k0 + kk < K) Ppart[((size_t)blockIdx.x * T + t_begin + tl) * K + k0 + kk] = s;
     }
 }
 
@@ -200,9 +199,9 @@ __global__ __launch_bounds__(kBlock) void write_kernel(const float2* __restrict_
 template <int M, int KP>
 hipError_t launch_power_one(hipStream_t s, const float2* X, const float2* What, float* Ppart, int T, int F, int K,
                             const PowGeom& g) {
-    dim3 grid(g.bxn ? g.bxn : g.nb, g.nsplit, (K + KP - 1) / KP);
+    dim3 grid(g.nb, g.nsplit, (K + KP - 1) / KP);
     const size_t shmem = (size_t)kWaves * g.tcp * KP * sizeof(float);
-    hipLaunchKernelGGL((power_kernel<M, KP>), grid, dim3(kBlock), shmem, s, X, What, Ppart, T, F, K, g.tcp, g.bx0);
+    hipLaunchKernelGGL((power_kernel<M, KP>), grid, dim3(kBlock), shmem, s, X, What, Ppart, T, F, K, g.tcp);
     return hipGetLastError();
 }
 

@@ -68,8 +68,8 @@ __global__ __launch_bounds__(kBlock) void update_kernel(UpdateArgs a) {
     const int tid = threadIdx.x;
     const int i = tid % SG;
     const int grp = tid / SG;
-    const int f_raw = a.f0 + blockIdx.x * (kBlock / SG) + grp;
-    const bool fvalid = f_raw < update_end(a);
+    const int f_raw = blockIdx.x * (kBlock / SG) + grp;
+    const bool fvalid = f_raw < a.F;
     const int f = fvalid ? f_raw : a.F - 1;
     const int M = MT ? MT : a.M, K = KT ? KT : a.K;   // compile-time constants fold the run-time predicates
     const int NA = M * M;
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(kBlock) void update_sq_kernel(UpdateArgs a) {
     const int tid = threadIdx.x;
     const Sq<MP, R> sq(tid % G);
     const int i = sq.i, j = sq.j;
-    const int f_raw = a.f0 + blockIdx.x * (kBlock / G) + tid / G;
-    const bool fvalid = f_raw < update_end(a);
+    const int f_raw = blockIdx.x * (kBlock / G) + tid / G;
+    const bool fvalid = f_raw < a.F;
     const int f = fvalid ? f_raw : a.F - 1;
     const int M = MT ? MT : a.M, K = KT ? KT : a.K;
     const int NA = M * M;
@@ -381,8 +381,8 @@ __global__ __launch_bounds__(kBlock) void update_bg_kernel(UpdateArgs a) {
     const int tid = threadIdx.x;
     const Sq<MP, R> sq(tid % G);
     const int i = sq.i, j = sq.j;
-    const int f_raw = a.f0 + blockIdx.x * (kBlock / G) + tid / G;
-    const bool fvalid = f_raw < update_end(a);
+    const int f_raw = blockIdx.x * (kBlock / G) + tid / G;
+    const bool fvalid = f_raw < a.F;
     const int f = fvalid ? f_raw : a.F - 1;
     const int M = MT ? MT : a.M;
     const int NA = M * M;
@@ -442,8 +442,8 @@ __global__ __launch_bounds__(kBlock) void update_det_kernel(UpdateArgs a) {
     const int tid = threadIdx.x;
     const Sq<MP, R> sq(tid % G);
     const int i = sq.i, j = sq.j;
-    const int f_raw = a.f0 + blockIdx.x * (kBlock / G) + tid / G;
-    const bool fvalid = f_raw < update_end(a);
+    const int f_raw = blockIdx.x * (kBlock / G) + tid / G;
+    const bool fvalid = f_raw < a.F;
     const int f = fvalid ? f_raw : a.F - 1;
     const int M = MT ? MT : a.M;
     const int NA = M * M;
@@ -532,8 +532,8 @@ __global__ __launch_bounds__(kBlock) void update_gram_kernel(UpdateArgs a) {
     const int tid = threadIdx.x;
     const Sq<MP, R> sq(tid % G_);
     const int i = sq.i, j = sq.j;
-    const int f_raw = a.f0 + blockIdx.x * (kBlock / G_) + tid / G_;
-    const bool fvalid = f_raw < update_end(a);
+    const int f_raw = blockIdx.x * (kBlock / G_) + tid / G_;
+    const bool fvalid = f_raw < a.F;
     const int f = fvalid ? f_raw : a.F - 1;
     const int M = MT ? MT : a.M, K = KT ? KT : a.K;
     const int NA = M * M;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(kBlock) void update_gram_kernel(UpdateArgs a) {
 template <int MP, int MT, int KT>
 hipError_t launch_gram_one(hipStream_t s, const UpdateArgs& a) {
     const int bins_per_block = kBlock / (MP * MP);
-    dim3 grid((update_end(a) - a.f0 + bins_per_block - 1) / bins_per_block);
+    dim3 grid((a.F + bins_per_block - 1) / bins_per_block);
     hipLaunchKernelGGL((update_gram_kernel<MP, MT, KT>), grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
@@ -638,7 +638,7 @@ hipError_t launch_gram_one(hipStream_t s, const UpdateArgs& a) {
 template <int MP, int MT>
 hipError_t launch_det_one(hipStream_t s, const UpdateArgs& a) {
     const int bins_per_block = kBlock / (MP * MP);
-    dim3 grid((update_end(a) - a.f0 + bins_per_block - 1) / bins_per_block);
+    dim3 grid((a.F + bins_per_block - 1) / bins_per_block);
     hipLaunchKernelGGL((update_det_kernel<MP, double, MT>), grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
@@ -646,7 +646,7 @@ hipError_t launch_det_one(hipStream_t s, const UpdateArgs& a) {
 template <int MP, int MT, int KT>
 hipError_t launch_sq_one(hipStream_t s, const UpdateArgs& a) {
     const int bins_per_block = kBlock / (MP * MP);
-    dim3 grid((update_end(a) - a.f0 + bins_per_block - 1) / bins_per_block);
+    dim3 grid((a.F + bins_per_block - 1) / bins_per_block);
     if (a.use_double)
         hipLaunchKernelGGL((update_sq_kernel<MP, double, MT, KT>), grid, dim3(kBlock), 0, s, a);
     else
@@ -659,7 +659,7 @@ hipError_t launch_sq_one(hipStream_t s, const UpdateArgs& a) {
 template <int MP, int MT, int KT>
 hipError_t launch_bg_one(hipStream_t s, const UpdateArgs& a) {
     const int bins_per_block = kBlock / (MP * MP);
-    dim3 grid((update_end(a) - a.f0 + bins_per_block - 1) / bins_per_block);
+    dim3 grid((a.F + bins_per_block - 1) / bins_per_block);
     if (a.use_double)
         hipLaunchKernelGGL((update_bg_kernel<MP, double, MT, KT>), grid, dim3(kBlock), 0, s, a);
     else
@@ -720,7 +720,7 @@ hipError_t launch_sq(hipStream_t s, const UpdateArgs& a) {
 template <int SG, int MT, int KT>
 hipError_t launch_sg_one(hipStream_t s, const UpdateArgs& a) {
     const int bins_per_block = kBlock / SG;
-    dim3 grid((update_end(a) - a.f0 + bins_per_block - 1) / bins_per_block);
+    dim3 grid((a.F + bins_per_block - 1) / bins_per_block);
     if (a.use_double)
         hipLaunchKernelGGL((update_kernel<SG, double, MT, KT>), grid, dim3(kBlock), 0, s, a);
     else

@@ -63,7 +63,6 @@ hipError_t launch_dominant(Kern kernel, dim3 grid, dim3 block, size_t shmem, hip
 }
 
 struct CovGeom {
-    int bx0 = 0, bxn = 0;   // bin groups [bx0, bx0 + bxn) only (bxn = 0: all nbg) -- the kernels of kernels_cov.hip (up to 8 channels, float32)
     int nsplit;   // frame splits (grid.y)
     int tc;       // frames per split (multiple of 16)
     int kc;       // sources per pass (template KC)
@@ -75,7 +74,6 @@ struct CovGeom {
     int quad = 0; // 10/12/14/16 channels, few sources, float32: the vector-ALU kernel of kernels_cov_quad.hip (float64 partials)
 };
 struct PowGeom {
-    int bx0 = 0, bxn = 0;   // bin batches [bx0, bx0 + bxn) only (bxn = 0: all nb) -- power_kernel
     int nb;       // bin batches of 64 (grid.x)
     int nsplit;   // frame splits (grid.y)
     int tcp;      // frames per split (multiple of 4, <= kPowMaxFrames)
@@ -179,9 +177,7 @@ struct UpdateArgs {
     int init_only;        // 1: only (re)compute J from W and Cx
     int use_double;       // per-bin algebra in fp64
     int layout;           // 0: one lane per matrix element (M <= 8), 1: one lane per matrix row
-    int f0 = 0, f1 = 0;   // bins [f0, f1) of the plan's F only (f1 = 0: up to F) -- the kernels of kernels_update.hip (up to 8 channels)
 };
-__host__ __device__ inline int update_end(const UpdateArgs& a) { return a.f1 > 0 ? a.f1 : a.F; }
 // W_hat element idx: the float64 variants keep their own complex128 copy so that nothing is rounded to
 // float32 between iterations; the complex64 array is always written (the streaming kernels read it)
 template <typename R>

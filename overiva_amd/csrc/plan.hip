@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -47,9 +48,69 @@ namespace {
 int round_up(int a, int b) { return (a + b - 1) / b * b; }
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-constexpr int kGraphBatch = 8;       // iterations per captured graph
-constexpr int kSplitGraphBatch = 16; // ... of the two-branch form (the last update of a graph is not overlapped)
+constexpr int kGraphBatch = 8;       // iterations of the graph captured ahead of time (oiva_plan_use_graph)
+constexpr int kGraphMaxIters = 32;   // longest graph captured on demand: an iterate(n) call is ceil(n / 32) replays
+constexpr int kGraphCache = 6;       // captured lengths kept per plan
 
+}  // namespace
+
+// ---- large device buffers (X, Y, staging) come from a process-wide pool -------------------------------------------
+// The drop-in call creates and destroys a plan per call; hipMalloc + hipFree of the 524 MB of X and the 131 MB of Y at the
+// headline shape were ~2.5 ms of a 22 ms call.  Buffers of >= 16 MB go back to the pool instead of the driver (exact-size
+// reuse, per device), at most $OIVA_POOL_MB (default 2048) held; oiva_pool_trim() releases them.
+namespace {
+struct BigPool {
+    struct Entry {
+        void* p;
+        size_t bytes;
+        int dev;
+    };
+    std::mutex m;
+    std::vector<Entry> held;      // oldest first
+    size_t total = 0;
+};
+BigPool& big_pool() {
+    static BigPool* bp = new BigPool;      // (never destroyed: the HIP runtime may be gone when static destructors run)
+    return *bp;
+}
+constexpr size_t kPoolMinBytes = (size_t)16 << 20;
+size_t pool_cap_bytes() {
+    static const size_t cap = [] {
+        const char* v = std::getenv("OIVA_POOL_MB");
+        return (size_t)(v ? std::max(0, std::atoi(v)) : 2048) << 20;
+    }();
+    return cap;
+}
+hipError_t big_alloc(int dev, void** out, size_t bytes) {
+    if (bytes >= kPoolMinBytes) {
+        BigPool& bp = big_pool();
+        std::lock_guard<std::mutex> g(bp.m);
+        for (size_t i = bp.held.size(); i-- > 0;)
+            if (bp.held[i].dev == dev && bp.held[i].bytes == bytes) {
+                *out = bp.held[i].p;
+                bp.total -= bytes;
+                bp.held.erase(bp.held.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipMalloc(out, bytes);
+}
+void big_free(int dev, void* ptr, size_t bytes) {
+    if (!ptr) return;
+    if (bytes >= kPoolMinBytes && bytes <= pool_cap_bytes()) {
+        BigPool& bp = big_pool();
+        std::lock_guard<std::mutex> g(bp.m);
+        while (!bp.held.empty() && bp.total + bytes > pool_cap_bytes()) {
+            (void)hipFree(bp.held.front().p);
+            bp.total -= bp.held.front().bytes;
+            bp.held.erase(bp.held.begin());
+        }
+        bp.held.push_back({ptr, bytes, dev});
+        bp.total += bytes;
+        return;
+    }
+    (void)hipFree(ptr);
+}
 }  // namespace
 
 struct oiva_plan {
@@ -60,6 +121,7 @@ struct oiva_plan {
 
     const float2* X = nullptr;  // (T,F,M)
     float2* X_owned = nullptr;
+    size_t x_owned_bytes = 0, y_bytes = 0;      // (big_alloc / big_free)
     float2* X_pad = nullptr;    // (T, F, M + 1): X with a zero channel behind every bin's M, for the vector-ALU covariance kernels at 9/11/13/15 channels
     float2* What = nullptr;     // (F,M,M) complex64: what the streaming kernels read
     double2* What64 = nullptr;  // (F,M,M) complex128: carried between iterations by the float64 update
@@ -150,16 +212,7 @@ struct oiva_plan {
     float2* ck_what = nullptr;                  // oiva_plan_save_w: a copy of W_hat (and of its complex128 form) on the device
     double2* ck_what64 = nullptr;
     bool ck_valid = false, ck_what64_valid = false;
-    hipGraphExec_t graph_exec = nullptr;        // one iteration
-    hipGraphExec_t graph_batch_exec = nullptr;  // kGraphBatch iterations
-    // two-branch graphs (oiva_plan_set_split): the bins in two halves A | B, the per-bin update of a half on a second stream
-    // beside the streaming pass of the other half -- act, cov_A, [cov_B || update_A], [power_A || update_B], power_B
-    int split_mode = 0;
-    int split_fa = 0;                           // bins of half A (whole 64-bin batches)
-    CovGeom split_cov{};                        // frame splits of the half-size covariance launches
-    PowGeom split_pw{};
-    hipStream_t stream2 = nullptr;
-    hipEvent_t sp_ev[4] = {};                   // cov_A done, cov_B done, update_A done, update_B done
+    std::vector<std::pair<int, hipGraphExec_t>> graphs;   // (iterations, executable graph), most recently used last
     hipEvent_t ev[2] = {};
 };
 
@@ -332,13 +385,10 @@ void choose_pow_geom(oiva_plan* p, int nsplit_req) {
 }
 
 int drop_graph(oiva_plan* p) {
-    if (p->graph_exec) {
-        HIP_TRY(hipGraphExecDestroy(p->graph_exec));
-        p->graph_exec = nullptr;
-    }
-    if (p->graph_batch_exec) {
-        HIP_TRY(hipGraphExecDestroy(p->graph_batch_exec));
-        p->graph_batch_exec = nullptr;
+    while (!p->graphs.empty()) {
+        hipGraphExec_t g = p->graphs.back().second;
+        p->graphs.pop_back();
+        HIP_TRY(hipGraphExecDestroy(g));
     }
     if (p->og_graph) {
         HIP_TRY(hipGraphExecDestroy(p->og_graph));
@@ -529,7 +579,7 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     }
     // nobody gave up: the staged W_hat becomes the state -- the buffers change places (captured graphs of the four-launch path
     // hold the old addresses: dropped, they are rebuilt if that path is ever used)
-    if (p->graph_exec || p->graph_batch_exec || p->og_graph) {
+    if (!p->graphs.empty() || p->og_graph) {
         int rcg = drop_graph(p);
         if (rcg) return rcg;
     }
@@ -545,140 +595,55 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
     return OIVA_OK;
 }
 
-// ---- two-branch iteration (oiva_plan_set_split) ---------------------------------------------------------
-bool split_applies(const oiva_plan* p) {
-    return p->split_mode && p->use_graph && p->M <= 8 && !p->cov_f64() && !p->cov.pair32 && !(p->prec & OIVA_PREC_UPDATE_ROWS) &&
-           p->pw.nb >= 2 && !p->raw_weights;
-}
-
-// geometry of the half-size launches: what the plan would choose for a shard of half the bins
-int split_setup(oiva_plan* p) {
-    if (!p->stream2) HIP_TRY(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
-    for (auto& e : p->sp_ev)
-        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    const int F = p->F;
-    const CovGeom cov = p->cov;
-    const PowGeom pw = p->pw;
-    p->split_fa = (p->pw.nb / 2) * kBinsPerWave * kWaves;
-    p->F = p->split_fa;
-    choose_cov_geom(p, 0);
-    choose_pow_geom(p, 0);
-    p->split_cov = p->cov;
-    p->split_pw = p->pw;
-    p->F = F;
-    p->cov = cov;
-    p->pw = pw;
-    if (p->split_cov.nsplit > p->vpart_splits_alloc) {
-        const int keep = p->cov.nsplit;
-        p->cov.nsplit = p->split_cov.nsplit;
-        int rc = ensure_vpart(p);
-        p->cov.nsplit = keep;
-        if (rc) return rc;
-    }
-    return OIVA_OK;
-}
-
-int capture_split(oiva_plan* p, int iters, hipGraphExec_t* exec) {
-    const int nbA = p->pw.nb / 2, nbB = p->pw.nb - nbA;
-    const int gA = p->split_fa / kBinsPerWave, gB = p->cov.nbg - gA;
-    PowGeom pwA = p->split_pw, pwB = p->split_pw;
-    pwA.bx0 = 0, pwA.bxn = nbA, pwB.bx0 = nbA, pwB.bxn = nbB;
-    CovGeom cA = p->split_cov, cB = p->split_cov;
-    cA.bx0 = 0, cA.bxn = gA, cB.bx0 = gA, cB.bxn = gB;
-    cA.nbg = cB.nbg = p->cov.nbg;
-    UpdateArgs ua;
-    ua.What = p->What;
-    ua.What64 = p->upd_f64() ? p->What64 : nullptr;
-    ua.Cx = p->Cx;
-    ua.Vpart = p->Vpart;
-    ua.vpart_f64 = p->vpart_f64() ? 1 : 0;
-    ua.wscale = p->wscale;
-    ua.nsplit = p->split_cov.nsplit;
-    ua.T = p->T, ua.F = p->F, ua.M = p->M, ua.K = p->K;
-    ua.init_only = 0;
-    ua.use_double = p->upd_f64() ? 1 : 0;
-    ua.layout = 0;
-    UpdateArgs uA = ua, uB = ua;
-    uA.f0 = 0, uA.f1 = p->split_fa, uB.f0 = p->split_fa, uB.f1 = p->F;
-    hipEvent_t evA = p->sp_ev[0], evB = p->sp_ev[1], evUA = p->sp_ev[2], evUB = p->sp_ev[3];
-    const float2* xpad = nullptr;
-    hipGraph_t graph = nullptr;
-    HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-    hipError_t e = hipSuccess;
-    int rc = OIVA_OK;
-    for (int i = 0; i < iters && e == hipSuccess && rc == OIVA_OK; ++i) {
-        if (i > 0) e = hipStreamWaitEvent(p->stream, evUA, 0);
-        if (e == hipSuccess) e = launch_power(p->stream, p->X, xpad, p->What, p->Ppart, p->T, p->F, p->M, p->K, pwA);
-        if (e == hipSuccess && i > 0) e = hipStreamWaitEvent(p->stream, evUB, 0);
-        if (e == hipSuccess) e = launch_power(p->stream, p->X, xpad, p->What, p->Ppart, p->T, p->F, p->M, p->K, pwB);
-        if (e == hipSuccess) rc = stage_activation(p, p->Ppart, p->pw.nb);
-        if (rc) break;
-        e = launch_cov(p->stream, p->X, nullptr, p->R, p->Plocal, p->wscale, p->model, 0, p->Vpart, false, p->T, p->F, p->M, p->K, cA);
-        if (e == hipSuccess) e = hipEventRecord(evA, p->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(p->stream2, evA, 0);
-        if (e == hipSuccess) e = launch_update(p->stream2, uA);
-        if (e == hipSuccess) e = hipEventRecord(evUA, p->stream2);
-        if (e == hipSuccess) e = launch_cov(p->stream, p->X, nullptr, p->R, p->Plocal, p->wscale, p->model, 0, p->Vpart, false, p->T, p->F, p->M, p->K, cB);
-        if (e == hipSuccess) e = hipEventRecord(evB, p->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(p->stream2, evB, 0);
-        if (e == hipSuccess) e = launch_update(p->stream2, uB);
-        if (e == hipSuccess) e = hipEventRecord(evUB, p->stream2);
-    }
-    if (e == hipSuccess && rc == OIVA_OK) e = hipStreamWaitEvent(p->stream, evUB, 0);      // join
-    hipError_t ec = hipStreamEndCapture(p->stream, &graph);
-    if (rc || e != hipSuccess || ec != hipSuccess) {
-        if (graph) (void)hipGraphDestroy(graph);
-        if (rc) return rc;
-        HIP_TRY(e);
-        HIP_TRY(ec);
-    }
-    e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    HIP_TRY(e);
-    HIP_TRY(hipGraphUpload(*exec, p->stream));
-    return OIVA_OK;
-}
-
-// Capture (stream capture records, it does not execute) and instantiate the two graphs an iterate() call
-// replays: kGraphBatch iterations (amortises the ~10-16 us replay floor, which matters when an iteration is tens
-// of microseconds) and a single iteration for the remainder.  Called from oiva_plan_use_graph when the plan
-// is ready and lazily from oiva_plan_iterate, so that no capture ever lands inside a caller's timed region.
-int build_graphs(oiva_plan* p) {
-    auto capture = [&](int iters, hipGraphExec_t* exec) -> int {
-        hipGraph_t graph = nullptr;
-        HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-        int r = OIVA_OK;
-        for (int i = 0; i < iters && r == OIVA_OK; ++i) r = one_iteration(p);
-        hipError_t e = hipStreamEndCapture(p->stream, &graph);
-        if (r) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return r;
+// The executable graph of `iters` iterations (stream capture records, it does not execute): taken from the plan's cache or
+// captured, instantiated and uploaded now.  An iterate(n) call replays ONE graph of n iterations (n <= 32; else 32 at a time):
+// a replay costs 10-16 us of which little hides behind the previous one, so the 20 steps of the driver's bench line as
+// 8 + 8 + 1 + 1 + 1 + 1 (rounds 1-4) ran 4.7 us per iteration above the steady state of the same kernels (205.1 against 200.4
+// us).  oiva_plan_use_graph captures the 8-iteration graph ahead of time, so that short calls never capture inside a
+// caller's timed region; other lengths are captured by the first call that asks for them (0.1-0.4 ms) and kept.
+int graph_for(oiva_plan* p, int iters, hipGraphExec_t* out) {
+    for (size_t i = 0; i < p->graphs.size(); ++i)
+        if (p->graphs[i].first == iters) {
+            auto hit = p->graphs[i];
+            p->graphs.erase(p->graphs.begin() + (long)i);
+            p->graphs.push_back(hit);
+            *out = hit.second;
+            return OIVA_OK;
         }
-        HIP_TRY(e);
-        e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        HIP_TRY(e);
-        // move the executable graph to the device now: otherwise its FIRST launch pays for that, inside whatever the
-        // caller is timing (a few percent of a 20-iteration run)
-        HIP_TRY(hipGraphUpload(*exec, p->stream));
-        return OIVA_OK;
-    };
     const bool pending = p->wscale_pending;
     const int raw = p->raw_weights;
-    int rc = OIVA_OK;
-    if (split_applies(p)) {
-        if (!p->graph_batch_exec || !p->graph_exec) rc = split_setup(p);
-        if (!rc && !p->graph_batch_exec) rc = capture_split(p, kSplitGraphBatch, &p->graph_batch_exec);
-        if (!rc && !p->graph_exec) rc = capture_split(p, 1, &p->graph_exec);
-        p->wscale_pending = pending;
-        p->raw_weights = raw;
-        return rc;
-    }
-    if (!p->graph_batch_exec) rc = capture(kGraphBatch, &p->graph_batch_exec);
-    if (!rc && !p->graph_exec) rc = capture(1, &p->graph_exec);
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+    int r = OIVA_OK;
+    for (int i = 0; i < iters && r == OIVA_OK; ++i) r = one_iteration(p);
+    hipError_t e = hipStreamEndCapture(p->stream, &graph);
     p->wscale_pending = pending;   // capturing toggled the host-side flags without running anything
     p->raw_weights = raw;
-    return rc;
+    if (r) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return r;
+    }
+    HIP_TRY(e);
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HIP_TRY(e);
+    // move the executable graph to the device now: otherwise its FIRST launch pays for that, inside whatever the
+    // caller is timing (a few percent of a 20-iteration run)
+    HIP_TRY(hipGraphUpload(exec, p->stream));
+    if ((int)p->graphs.size() >= kGraphCache) {
+        HIP_TRY(hipStreamSynchronize(p->stream));          // (the evicted graph may still be replaying)
+        HIP_TRY(hipGraphExecDestroy(p->graphs.front().second));
+        p->graphs.erase(p->graphs.begin());
+    }
+    p->graphs.emplace_back(iters, exec);
+    *out = exec;
+    return OIVA_OK;
+}
+
+int build_graphs(oiva_plan* p) {
+    hipGraphExec_t g = nullptr;
+    return graph_for(p, kGraphBatch, &g);
 }
 
 // W_hat lives twice on the device: complex64 for the streaming kernels, complex128 for the float64 update
@@ -841,12 +806,18 @@ int oiva_plan_destroy(oiva_plan* p) {
     if (!p) return OIVA_OK;
     DeviceGuard guard(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    if (p->graph_batch_exec) (void)hipGraphExecDestroy(p->graph_batch_exec);
+    for (auto& g : p->graphs) (void)hipGraphExecDestroy(g.second);
     if (p->og_graph) (void)hipGraphExecDestroy(p->og_graph);
     if (p->res_code_host) (void)hipHostFree(p->res_code_host);
-    void* bufs[] = {p->X_owned, p->X_pad, p->What, p->What64, p->Cx,        p->Vpart,    p->Ppart, p->Plocal, p->res_block, p->res_trace_buf, p->res_what, p->res_what64,
-                    p->R,       p->wscale, p->Spart, p->Y,      p->scratch_c, p->scratch_p};
+    if (p->io_stream) (void)hipStreamSynchronize(p->io_stream);
+    big_free(p->device, p->X_owned, p->x_owned_bytes);
+    big_free(p->device, p->Y, p->y_bytes);
+    for (int i = 0; i < kHostRingSlots; ++i) {
+        big_free(p->device, p->io_c128[i], p->io_c128_bytes);
+        p->io_c128[i] = nullptr;
+    }
+    void* bufs[] = {p->X_pad, p->What, p->What64, p->Cx,        p->Vpart,    p->Ppart, p->Plocal, p->res_block, p->res_trace_buf, p->res_what, p->res_what64,
+                    p->R,       p->wscale, p->Spart, p->scratch_c, p->scratch_p};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (void* b : p->og_bufs)
@@ -856,13 +827,9 @@ int oiva_plan_destroy(oiva_plan* p) {
     if (p->fx_state) (void)hipFree(p->fx_state);
     if (p->fx_flag_host) (void)hipHostFree(p->fx_flag_host);
     if (p->io_stream) (void)hipStreamDestroy(p->io_stream);
-    if (p->stream2) (void)hipStreamDestroy(p->stream2);
-    for (auto& e : p->sp_ev)
-        if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < kHostRingSlots; ++i) {
         if (p->io_written[i]) (void)hipEventDestroy(p->io_written[i]);
         if (p->io_copied[i]) (void)hipEventDestroy(p->io_copied[i]);
-        if (p->io_c128[i]) (void)hipFree(p->io_c128[i]);
     }
     if (p->ck_what) (void)hipFree(p->ck_what);
     if (p->ck_what64) (void)hipFree(p->ck_what64);
@@ -879,7 +846,10 @@ int oiva_plan_set_x_host(oiva_plan* p, const void* X, long long row_pitch_bytes)
     const size_t row = (size_t)p->F * p->M * sizeof(float2);
     const size_t pitch = row_pitch_bytes > 0 ? (size_t)row_pitch_bytes : row;
     NEED(pitch >= row, OIVA_ERR_ARG, "row pitch smaller than one frame of this plan's bins");
-    if (!p->X_owned) HIP_TRY(hipMalloc(&p->X_owned, row * p->T));
+    if (!p->X_owned) {
+        HIP_TRY(big_alloc(p->device, (void**)&p->X_owned, row * p->T));
+        p->x_owned_bytes = row * p->T;
+    }
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemcpy2D(p->X_owned, row, X, pitch, row, p->T, hipMemcpyHostToDevice));
     if (p->X != p->X_owned) {             // switching from a borrowed array: captured graphs hold its pointer
@@ -900,13 +870,16 @@ int oiva_plan_set_x_host_c128(oiva_plan* p, const void* X, long long row_pitch_b
     const size_t row = n_row * sizeof(double2);
     const size_t pitch = row_pitch_bytes > 0 ? (size_t)row_pitch_bytes : row;
     NEED(pitch >= row, OIVA_ERR_ARG, "row pitch smaller than one frame of this plan's bins");
-    if (!p->X_owned) HIP_TRY(hipMalloc(&p->X_owned, n_row * sizeof(float2) * p->T));
+    if (!p->X_owned) {
+        HIP_TRY(big_alloc(p->device, (void**)&p->X_owned, n_row * sizeof(float2) * p->T));
+        p->x_owned_bytes = n_row * sizeof(float2) * p->T;
+    }
     HIP_TRY(hipStreamSynchronize(p->stream));
     // in slabs of frames through a staging buffer (<= 256 MB): the conversion of one slab overlaps nothing, but the
     // footprint stays bounded and the host never touches the data (a NumPy astype of 1 GB costs 60 ms)
     const int slab = (int)std::max<size_t>(1, std::min<size_t>((size_t)p->T, ((size_t)256 << 20) / row));
     double2* stage = nullptr;
-    HIP_TRY(hipMalloc(&stage, row * slab));
+    HIP_TRY(big_alloc(p->device, (void**)&stage, row * slab));
     hipError_t e = hipSuccess;
     for (int t0 = 0; t0 < p->T && e == hipSuccess; t0 += slab) {
         const int nt = std::min(slab, p->T - t0);
@@ -914,7 +887,7 @@ int oiva_plan_set_x_host_c128(oiva_plan* p, const void* X, long long row_pitch_b
         if (e == hipSuccess) e = launch_cast_c128_to_c64(p->stream, stage, p->X_owned + (size_t)t0 * n_row, (long long)nt * n_row);
         if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
     }
-    (void)hipFree(stage);
+    if (e == hipSuccess) big_free(p->device, stage, row * slab); else (void)hipFree(stage);
     HIP_TRY(e);
     if (p->X != p->X_owned) {             // switching from a borrowed array: captured graphs hold its pointer
         int rc = drop_graph(p);
@@ -1033,7 +1006,10 @@ int oiva_plan_demix_dev(oiva_plan* p, int proj_back, void** Y_dev) {
     DeviceGuard guard(p->device);
     if ((rc = check_fused(p))) return rc;
     const size_t row = (size_t)p->F * p->K * sizeof(float2);
-    if (!p->Y) HIP_TRY(hipMalloc(&p->Y, row * p->T));
+    if (!p->Y) {
+        HIP_TRY(big_alloc(p->device, (void**)&p->Y, row * p->T));
+        p->y_bytes = row * p->T;
+    }
     const float* sp = nullptr;
     if (proj_back) {
         HIP_TRY(launch_demix_stats(p->stream, p->X, p->What, p->Spart, p->T, p->F, p->M, p->K, p->stg));
@@ -1060,11 +1036,13 @@ int oiva_plan_iterate(oiva_plan* p, int n) {
         if (ran) return OIVA_OK;
     }
     if (p->use_graph) {
-        if ((rc = build_graphs(p))) return rc;
-        int left = n;
-        const int batch = split_applies(p) ? kSplitGraphBatch : kGraphBatch;
-        for (; left >= batch; left -= batch) HIP_TRY(hipGraphLaunch(p->graph_batch_exec, p->stream));
-        for (; left > 0; --left) HIP_TRY(hipGraphLaunch(p->graph_exec, p->stream));
+        for (int left = n; left > 0;) {
+            const int m = std::min(left, kGraphMaxIters);
+            hipGraphExec_t g = nullptr;
+            if ((rc = graph_for(p, m, &g))) return rc;
+            HIP_TRY(hipGraphLaunch(g, p->stream));
+            left -= m;
+        }
         p->wscale_pending = false;
         return OIVA_OK;
     }
@@ -1129,7 +1107,10 @@ static int demix_to_host(oiva_plan* p, void* Y_host, long long row_pitch_bytes, 
     const size_t pitch = row_pitch_bytes > 0 ? (size_t)row_pitch_bytes : row;
     NEED(pitch >= row, OIVA_ERR_ARG, "row pitch smaller than one frame of this plan's bins");
     if ((rc = check_fused(p))) return rc;
-    if (!p->Y) HIP_TRY(hipMalloc(&p->Y, row_dev * p->T));
+    if (!p->Y) {
+        HIP_TRY(big_alloc(p->device, (void**)&p->Y, row_dev * p->T));
+        p->y_bytes = row_dev * p->T;
+    }
     const float* sp = nullptr;
     if (proj_back) {
         HIP_TRY(launch_demix_stats(p->stream, p->X, p->What, p->Spart, p->T, p->F, p->M, p->K, p->stg));
@@ -1175,10 +1156,11 @@ static int demix_to_host(oiva_plan* p, void* Y_host, long long row_pitch_bytes, 
         if (!p->io_copied[i]) HIP_TRY(hipEventCreateWithFlags(&p->io_copied[i], hipEventDisableTiming));
     }
     if (c128 && p->io_c128_bytes < slab_bytes) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
         for (auto& b : p->io_c128) {
-            if (b) HIP_TRY(hipFree(b));
+            big_free(p->device, b, p->io_c128_bytes);
             b = nullptr;
-            HIP_TRY(hipMalloc((void**)&b, slab_bytes));
+            HIP_TRY(big_alloc(p->device, (void**)&b, slab_bytes));
         }
         p->io_c128_bytes = slab_bytes;
     }
@@ -1232,6 +1214,21 @@ static int demix_to_host(oiva_plan* p, void* Y_host, long long row_pitch_bytes, 
         }
     }
     return finish(hipStreamSynchronize(p->stream));
+}
+
+int oiva_pool_trim(void) {
+    BigPool& bp = big_pool();
+    std::lock_guard<std::mutex> g(bp.m);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (auto& e : bp.held) {
+        (void)hipSetDevice(e.dev);
+        (void)hipFree(e.p);
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    bp.held.clear();
+    bp.total = 0;
+    return OIVA_OK;
 }
 
 int oiva_plan_set_io_slab(oiva_plan* p, long long bytes) {
@@ -1546,16 +1543,6 @@ int oiva_plan_set_pow_splits(oiva_plan* p, int nsplit) {
     int rc = drop_graph(p);
     if (rc) return rc;
     choose_pow_geom(p, nsplit);
-    return OIVA_OK;
-}
-
-int oiva_plan_set_split(oiva_plan* p, int mode) {
-    NEED(p && (mode == 0 || mode == 1), OIVA_ERR_ARG, "bad arguments");
-    DeviceGuard guard(p->device);
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    int rc = drop_graph(p);
-    if (rc) return rc;
-    p->split_mode = mode;
     return OIVA_OK;
 }
 

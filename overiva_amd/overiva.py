@@ -59,6 +59,14 @@ def get_precision():
     return _precision
 
 
+def release_cached_buffers():
+    """give the large device buffers the library keeps between calls (copies of X and Y of destroyed plans, at most
+    $OIVA_POOL_MB = 2048 MB) back to the driver"""
+    from . import _lib
+
+    _lib.check(_lib.load().oiva_pool_trim())
+
+
 _last_info = {}
 
 
@@ -165,15 +173,6 @@ def overiva(
                                           exchange=group[1] if len(group) > 1 else None)
     else:
         solver = _SingleDevice(n_frames, n_freq, n_chan, n_src, model, precision)
-    # the array the call returns, allocated now and its pages faulted in by the library's copy threads WHILE X is uploaded and
-    # the iterations run: the final hand-over (131 MB at the headline shape) then meets resident pages (csrc/host_io.hip)
-    out, prefault = None, None
-    if group is None and n_frames * n_freq * n_src * np.dtype(dtype).itemsize >= _PREFAULT_MIN_BYTES:
-        import threading
-
-        out = np.empty((n_frames, n_freq, n_src), dtype)
-        prefault = threading.Thread(target=_prefault, args=(out,), daemon=True)
-        prefault.start()
     try:
         solver.set_x(X)
         solver.covariance()
@@ -193,8 +192,13 @@ def overiva(
             solver.iterate(step)
             epoch += step
 
-        if prefault is not None:
-            prefault.join()
+        if group is None and n_frames * n_freq * n_src * np.dtype(dtype).itemsize >= _PREFAULT_MIN_BYTES:
+            # the array the call returns: allocated, and its pages faulted in by the library's copy threads, while the GPU still
+            # runs the iterations queued above (1-2 ms for the 131 MB of the headline shape, hidden behind 4 ms of kernels);
+            # the hand-over then meets resident pages: 41 GB/s instead of 23-32 (tools/e2e_phases.py; csrc/host_io.hip).
+            # (Beside the upload of X instead -- from a thread -- it slowed the upload by as much as it saved.)
+            out = np.empty((n_frames, n_freq, n_src), dtype)
+            _prefault(out)
             Y = solver.demix(proj_back, dtype, out=out)
         else:
             Y = solver.demix(proj_back, dtype)

@@ -238,11 +238,6 @@ class Plan:
     def use_graph(self, enable=True):
         _lib.check(self.lib.oiva_plan_use_graph(self.h, 1 if enable else 0))
 
-    def set_split(self, mode=1):
-        """two-branch graphs: the per-bin update of one half of the bins beside the streaming pass of the other half (see
-        ``oiva_plan_set_split``); needs ``use_graph``"""
-        _lib.check(self.lib.oiva_plan_set_split(self.h, int(mode)))
-
     def set_precision(self, mode="fast", row_layout=False):
         """``"fast"`` (float32 products, lane chains and per-bin algebra), ``"mixed"`` (float32 products and lane
         chains of the covariance pass, float64 sums across lanes / splits and float64 per-bin algebra, W_hat carried in

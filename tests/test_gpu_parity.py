@@ -632,35 +632,10 @@ def test_graph_replay_equals_eager(oa):
             p.set_w(None)
             p.iterate(3)
             p.iterate(2)
-            p.iterate(19)          # 2 batches of 8 iterations + 3 single replays
+            p.iterate(19)          # one replayed graph per call (cached by length), 40: 32 + 8
+            p.iterate(40)
             outs.append(p.get_w())
     assert np.array_equal(outs[0], outs[1])
-
-
-@pytest.mark.parametrize("shape", [(1000, 513, 4, 2), (300, 200, 6, 3), (500, 128, 8, 8), (4000, 512, 8, 2), (257, 130, 5, 1), (200, 64, 2, 2)])
-@pytest.mark.parametrize("mode", ["mixed", "fast"])
-def test_two_branch_graphs_give_the_bits_of_one_stream(oa, shape, mode):
-    """oiva_plan_set_split: the bins in two halves, the per-bin update of one half on a second stream beside the streaming pass of
-    the other (overiva.py:176-190 is per bin; only :152-155 couples the bins): the same kernels on bin ranges, so W is the
-    one-stream result bit for bit -- graphs of 16 iterations, single ones, several calls; also with the in-kernel exchange
-    in loop-back"""
-    T, F, M, K = shape
-    X = orc.synth_iid(T, F, M, seed=3)
-    outs = []
-    for split, loop in ((0, 0), (1, 0), (1, 2)):
-        with _plan(oa, X, K, mode=mode) as p:
-            p.set_w(None)
-            if loop:
-                p.fused_loopback(loop)
-            p.use_graph(True)
-            p.set_split(split)
-            p.iterate(3)
-            p.iterate(17)
-            p.iterate(16)
-            p.sync()
-            outs.append(p.get_w(np.complex128))
-    assert np.all(np.isfinite(outs[0]))
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 # --------------------------------------------------------------------------------------------
