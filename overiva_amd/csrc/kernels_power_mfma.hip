@@ -8,6 +8,8 @@
 //   never stored.  The VALU kernel needs K/4 passes over X at K = 16 (register budget); this one reads X once.
 #include "oiva_device.h"
 
+#include <cstdlib>
+
 namespace oiva {
 namespace {
 
@@ -147,6 +149,150 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product with X staged through LDS (16 channels, whole 64-bin batches).  power_mfma_kernel asks memory for 128-byte
+// runs 262 KB apart (lane = frame: 16 frames x one bin per load instruction) and reaches 0.56 of the HBM peak; the vector-ALU
+// power_kernel<16, 2>, whose loads are 2 KB runs (lane = bin), moves the same bytes at 0.74.  Here the loads are those 2 KB
+// runs -- one frame's 16 bins x 16 channels, by LDS-DMA, no staging registers -- and the matrix cores read their frame-major
+// operands back from LDS:
+//   workgroup = one 64-bin batch x kPlFrames frames; 16 steps = 4 sub-batches of 16 bins x 4 tiles of 16 frames;
+//   a step: 16 rows of 2 KB -> LDS (pitch 2 KB + 16 bytes: lane (frame j, quarter q) reads 32 bytes at row j -- the 16 frames
+//   of a read pass fall into 16 different bank groups); wave w multiplies bins 4w .. 4w + 3 of the sub-batch (W of its four
+//   bins in registers for the sub-batch's four steps); two buffers, the DMA of step s + 1 in flight behind the products of s;
+//   |y|^2 summed over the wave's bins in the accumulator layout, over the four waves through LDS at the end: the same
+//   64-bin parts as every other power kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kPlTiles = 4;                          // frame tiles of 16 per workgroup
+constexpr int kPlFrames = 16 * kPlTiles;
+constexpr int kPlRow = 16 * 16 * 8;                  // one frame's 16 bins x 16 channels
+constexpr int kPlPitch = kPlRow + 16;
+constexpr int kPlStage = 16 * kPlPitch;              // bytes per buffer
+
+typedef __attribute__((address_space(1))) const void gvoid_pl_t;
+typedef __attribute__((address_space(3))) void lvoid_pl_t;
+
+__global__ __launch_bounds__(kBlock, 2) void power_lds_kernel(const float2* __restrict__ X, const float2* __restrict__ What,
+                                                              float* __restrict__ Ppart, int T, int F, int K) {
+    constexpr int M = 16;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[2][kPlStage];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15;             // A: source (row) | B: frame (column)
+    const int q = lane >> 4;             // owner of channels 4q .. 4q + 3 (contraction index)
+    const int f0 = blockIdx.x * kBinsPerBatch;
+    const int t0 = blockIdx.y * kPlFrames;
+    const size_t frame_stride = (size_t)F * M;       // float2 per frame
+
+    // step s = (sub-batch sb = s >> 2, tile tl = s & 3): rows = frames t0 + 16 tl + r, r < 16; this wave requests rows
+    // 4 wave .. 4 wave + 3, each as two 1 KB halves (64 lanes x 16 bytes)
+    auto issue = [&](int s, int buf) {
+        const int sb = s >> 2, tl = s & 3;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr;
+            const int t = t0 + 16 * tl + r;
+            const float2* src = X + (size_t)(t < T ? t : T - 1) * frame_stride + (size_t)(f0 + 16 * sb) * M;   // (frames past T: a valid row, never stored)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                __builtin_amdgcn_global_load_lds((gvoid_pl_t*)(src + h * 128 + lane * 2), (lvoid_pl_t*)(stage[buf] + r * kPlPitch + h * 1024), 16, 0, 0);
+        }
+    };
+    float P[kPlTiles][4];                // sources 4q .. 4q + 3 at frame t0 + 16 tl + j, summed over this wave's bins
+#pragma unroll
+    for (int tl = 0; tl < kPlTiles; ++tl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[tl][r] = 0.f;
+
+    // LDS byte address of this lane's 32 bytes of (row j, first bin of the wave) in buffer 0
+    const unsigned rd_base = (unsigned)(uintptr_t)(&stage[0][0]) + j * kPlPitch + wave * 4 * 128 + q * 32;
+    issue(0, 0);
+    float2 w[4][4];                      // [bin of the wave][channel 4q + c]: W[f][m][k = j]
+    for (int sb = 0; sb < 4; ++sb) {
+        // W of this wave's four bins of the sub-batch (from L2; once per four steps).  Requested BEFORE the DMAs of the next
+        // step, so that the counted wait below covers it.
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float2 wv = What[((size_t)(f0 + 16 * sb + 4 * wave + g) * M + 4 * q + c) * M + (j < K ? j : 0)];
+                w[g][c] = make_float2(j < K ? wv.x : 0.f, j < K ? wv.y : 0.f);
+            }
+        static_for<kPlTiles>([&](auto tc) {
+            constexpr int tl = decltype(tc)::value;
+            const int s = 4 * sb + tl;
+            // buffer (s + 1) & 1 was read in step s - 1 and every wave has passed that step's second barrier
+            if (s + 1 < 16) issue(s + 1, (s + 1) & 1);
+            // this wave's eight requests of step s have landed (those of s + 1 -- and nothing else -- may still be in flight),
+            // then every wave's.  Raw barrier: __syncthreads() carries a release fence, which drains the DMA queue.
+            if (s + 1 < 16)
+                asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            float4 v[8];
+            // (the reads in assembly: hipcc puts a vmcnt(0) in front of every LDS read it can see behind an LDS-DMA)
+            asm volatile(
+                "ds_read_b128 %0, %8\n\t"
+                "ds_read_b128 %1, %8 offset:16\n\t"
+                "ds_read_b128 %2, %8 offset:128\n\t"
+                "ds_read_b128 %3, %8 offset:144\n\t"
+                "ds_read_b128 %4, %8 offset:256\n\t"
+                "ds_read_b128 %5, %8 offset:272\n\t"
+                "ds_read_b128 %6, %8 offset:384\n\t"
+                "ds_read_b128 %7, %8 offset:400\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "s_barrier"                   // every wave holds its operands: the buffer may be requested into again
+                : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                : "v"(rd_base + (unsigned)((s & 1) * kPlStage))
+                : "memory");
+            f32x4 yr[4], yi[4];
+            float2 x[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                x[g][0] = make_float2(v[2 * g].x, v[2 * g].y);
+                x[g][1] = make_float2(v[2 * g].z, v[2 * g].w);
+                x[g][2] = make_float2(v[2 * g + 1].x, v[2 * g + 1].y);
+                x[g][3] = make_float2(v[2 * g + 1].z, v[2 * g + 1].w);
+                yr[g] = yi[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // chunk-major over the four bins: eight independent accumulators, an MFMA never waits for the one before it
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    yr[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][c].x, x[g][c].x, yr[g], 0, 0, 0);
+                    yi[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][c].x, x[g][c].y, yi[g], 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    yr[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][c].y, x[g][c].y, yr[g], 0, 0, 0);
+                    yi[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(-w[g][c].y, x[g][c].x, yi[g], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[tl][r] = fmaf(yr[g][r], yr[g][r], fmaf(yi[g][r], yi[g][r], P[tl][r]));
+        });
+    }
+    __syncthreads();
+    // the four waves' sums (wave order) -> Ppart; D layout: lane l, register r = [source 4 (l >> 4) + r][frame l & 15]
+    float* red = reinterpret_cast<float*>(stage[0]);       // [wave][tile][source 16][frame 16]
+#pragma unroll
+    for (int tl = 0; tl < kPlTiles; ++tl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * kPlTiles + tl) * 16 + 4 * q + r) * 16 + j] = P[tl][r];
+    __syncthreads();
+    for (int e = tid; e < kPlFrames * 16; e += kBlock) {
+        const int tl = e >> 8, k = (e >> 4) & 15, jj = e & 15;      // consecutive threads: consecutive frames of one source
+        const int t = t0 + 16 * tl + jj;
+        float sum = red[((0 * kPlTiles + tl) * 16 + k) * 16 + jj];
+#pragma unroll
+        for (int wv = 1; wv < kWaves; ++wv) sum += red[((wv * kPlTiles + tl) * 16 + k) * 16 + jj];
+        if (t < T && k < K) Ppart[((size_t)blockIdx.x * T + t) * K + k] = sum;
+    }
+}
+
 }  // namespace
 
 template <int TILES, int GROUP>
@@ -168,6 +314,12 @@ hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What,
     // measured at 2048 x 4000 x 16 / 16 (tiles x bins per group): 4x1 252 us, 2x1 252, 2x2 267, 1x2 279, 1x4 306 -- the
     // W operands come from L2 once per wave and bin, so more frames per wave is less W traffic (W-only 81 us at 1x4);
     // X alone streams in 199 us, the MFMAs alone take 134 us
+    // 16 channels, whole 64-bin batches: X staged through LDS in 2 KB runs (power_lds_kernel above); $OIVA_POWER_LDS=0: off
+    static const bool lds = [] { const char* v = getenv("OIVA_POWER_LDS"); return !(v && v[0] == '0'); }();
+    if (lds && M == 16 && Mp == 16 && F % kBinsPerBatch == 0 && T >= 16) {
+        power_lds_kernel<<<dim3(F / kBinsPerBatch, (T + kPlFrames - 1) / kPlFrames), dim3(kBlock), 0, s>>>(X, What, Ppart, T, F, K);
+        return hipGetLastError();
+    }
     return launch_shape<4, 1>(s, X, What, Ppart, T, F, M, Mp, K);
 }
 

@@ -488,18 +488,16 @@ __global__ __launch_bounds__(kBlock) void update_det_kernel(UpdateArgs a) {
             const Cx<R> ui = sq.template rowb_c<s>(C);                 // u_i = C[i][s]
             const Cx<R> uj = sq.at(C, j, s);                           // u_j
             const Cx<R> wi = sq.rowsum(cmul(Vinv, uj));                // w = V^-1 u (not yet normalised), one entry per row
-            // d = w^H V_s w from V_s itself, as the reference forms it (overiva.py:185), and y_s = w^H u as its own (complex)
-            // quantity: with the exact w both are the same number, and round 4 used Re(y_s) for both -- on a W_hat that is
-            // not adapted to V_s (first iterations) and cond(V) = 1e10 that put the result 2e-4 from the reference's, whose
-            // own sensitivity there is 8e-7; with the two kept apart the form stays at that sensitivity up to cond 1e12
-            // (tests/test_update_forms.py; a step of iterative refinement on top changed nothing and is not done)
-            const Cx<R> ti = sq.rowsum(cmul(V, sq.transp(wi)));        // t = V w, one entry per row (0 outside M)
-            // d = w^H V w (overiva.py:185; real)
-            const R d = sq.allsum(j == 0 ? wi.re * ti.re + wi.im * ti.im : R(0));
-            // y = w^H C, one entry per column;  y_s = w^H u  (= d for the exact w)
+            // y = w^H C, one entry per column;  y_s = w^H u = w^H V w =: d  (overiva.py:185) -- real for the exact w.  The
+            // normalisation takes its real part; the Sherman-Morrison step below must divide by the COMPLEX y_s the rounded
+            // w really gives: round 4 divided by Re(y_s) there, and on a W_hat not yet adapted to V_s (first iterations) with
+            // cond(V) = 1e10 that put the result 2e-4 from the reference's, whose own sensitivity there is 8e-7; with the
+            // complex denominator the form stays at that sensitivity up to cond 1e12 (tests/test_update_forms.py; d from
+            // V itself on top of it, or a step of iterative refinement, changed nothing and is not done)
             const Cx<R> t = cmul(Cx<R>{wi.re, -wi.im}, C);
             Cx<R> y = {sq.colsum(t.re), sq.colsum(t.im)};
             const Cx<R> ys = sq.template rowb_c<s>(y);
+            const R d = ys.re;
             const R sc = fast_rsqrt(d);
             // row s of W_hat^H becomes w'^H, w' = w / sqrt(d): by Sherman-Morrison (exact for ANY w)
             //   C' = C - u (w'^H C - e_s^T) / (w'^H u) = C - (u / y_s) (y - sqrt(d) e_s^T)

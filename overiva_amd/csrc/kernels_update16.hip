@@ -583,9 +583,6 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
                 if (sgn[e] != 0.f) Vi[e].im = s.pk[off[e] + 1] * R(sgn[e]) * invT;
             }
         }
-        C2<R> Vs[4];                                             // V itself, for the residual below
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Vs[e] = Vi[e];
         herm_inverse(Vi);
         // u = column src of C: u_i for the row, u_c for the lane's four columns (through LDS)
         const int se = src >> 2, sq = src & 3;
@@ -617,10 +614,6 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
         // w = V^-1 u (not yet normalised)
         const C2<R> wi = matvec(Vi, s.w);
         publish(s.w, wi);
-        // t = V w for d = w^H V w as the reference forms it (overiva.py:185) -- not Re(w^H u): see update_det_kernel
-        const C2<R> ti = matvec(Vs, s.w);
-        // d = w^H V w (overiva.py:185; real)
-        const R d = wave_sum16(wi.re * ti.re + wi.im * ti.im);
         // y = w^H C: column sums over the 16 rows (lanes of equal q)
         C2<R> y[4];
 #pragma unroll
@@ -628,7 +621,9 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
             const C2<R> x = cmul(cconj(wi), C[e]);
             y[e] = {wave_sum16(x.re), wave_sum16(x.im)};
         }
-        // y_src = w^H u (= d for the exact w): held by the lanes q == sq in element se
+        // y_src = w^H u = w^H V w =: d (overiva.py:185; real for the exact w): the normalisation takes its real part, the
+        // Sherman-Morrison step divides by the COMPLEX value the rounded w gives (see update_det_kernel); held by the lanes
+        // q == sq in element se
         wave_lds_sync();
         if (lane == sq) {
             const C2<R> v = se == 0 ? y[0] : (se == 1 ? y[1] : (se == 2 ? y[2] : y[3]));
@@ -636,6 +631,7 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
         }
         wave_lds_sync();
         const C2<R> ys = s.ppiv;
+        const R d = ys.re;
         const R sc = R(1) / sqrt(d);
         // Sherman-Morrison for the new row src of W_hat^H (exact for any w): C' = C - (u / y_src) (y - sqrt(d) e_src^T)
         const C2<R> g = cmul(ui, cinv_fast(ys));

@@ -160,6 +160,35 @@ def test_power_pass_of_many_sources_at_every_channel_count(oa, shape, before_cov
     assert orc.rel_err(pw, orc.demix_power(X, What[:, :, :K])) < TOL_KERNEL
 
 
+@pytest.mark.parametrize("shape", [(100, 64, 16, 16), (64, 128, 16, 9), (37, 64, 16, 5), (16, 64, 16, 16), (1000, 192, 16, 13), (129, 64, 16, 8)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+def test_power_pass_through_lds_at_16_channels(oa, shape):
+    """power_lds_kernel (16 channels, more than 4 sources, whole 64-bin batches; overiva.py:140 + :153): X in 2 KB runs through
+    LDS to the matrix cores -- frame counts that are no multiple of the 64 frames of a workgroup or the 16 of a tile, every
+    source count, several batches; against the oracle and against the kernel it replaces ($OIVA_POWER_LDS=0 is read once per
+    process, so the other kernel is reached through a bin count that is no multiple of 64: the same bins plus one)"""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F + 1, M, seed=3)
+    rng = np.random.default_rng(6)
+    What = (rng.standard_normal((F + 1, M, M)) + 1j * rng.standard_normal((F + 1, M, M))).astype(np.complex64)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_x(np.ascontiguousarray(X[:, :F]))
+        p.covariance()
+        p.t_set_what(What[:F])
+        pw = p.t_run_power()
+    assert orc.rel_err(pw, orc.demix_power(X[:, :F], What[:F, :, :K])) < TOL_KERNEL
+    with oa.Plan(T, F + 1, M, K, "laplace") as p:          # the frame-major kernel (F + 1 bins: no whole batches)
+        p.set_x(X)
+        p.covariance()
+        p.t_set_what(What)
+        pw1 = p.t_run_power()
+    ref1 = orc.demix_power(X, What[:, :, :K])
+    assert orc.rel_err(pw1, ref1) < TOL_KERNEL
+    # the last bin's own contribution, from the oracle, takes one result to the other
+    last = orc.demix_power(X[:, F:], What[F:, :, :K])
+    assert orc.rel_err(pw1 - last, pw) < 2 * TOL_KERNEL
+
+
 @pytest.mark.needs("im_{model}_e0_s0_V")
 @pytest.mark.parametrize("rows", [False, True], ids=["lane-per-element", "lane-per-row"])
 @pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])

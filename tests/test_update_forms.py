@@ -60,9 +60,9 @@ def herm_inverse_unpivoted(A):
 
 
 def determined_as_the_kernels(W_hat, V, round4=False):
-    """update_det_kernel / update_det16_kernel step by step: unpivoted inverse of V_s, u from the maintained C, d = w^H V_s w
-    from V_s itself (overiva.py:185), C by Sherman-Morrison with the complex y_s = w^H u.
-    round4: the form of round 4, Re(y_s) in both places (equal in exact arithmetic)."""
+    """update_det_kernel / update_det16_kernel step by step: unpivoted inverse of V_s, u from the maintained C, d = Re(y_s) with
+    y_s = w^H u (= w^H V_s w, overiva.py:185), C by Sherman-Morrison with the COMPLEX y_s as its denominator.
+    round4: the form of round 4, Re(y_s) as the denominator too (equal in exact arithmetic)."""
     W_hat = W_hat.copy()
     F, M, _ = W_hat.shape
     C = np.linalg.inv(_herm(W_hat))
@@ -71,7 +71,7 @@ def determined_as_the_kernels(W_hat, V, round4=False):
         w = np.einsum("fij,fj->fi", herm_inverse_unpivoted(V[s]), u)
         y = np.einsum("fi,fij->fj", np.conj(w), C)
         ys = y[:, s].copy()
-        d = ys.real.copy() if round4 else np.einsum("fi,fij,fj->f", np.conj(w), V[s], w).real
+        d = ys.real.copy()
         W_hat[:, :, s] = w / np.sqrt(d)[:, None]
         y[:, s] -= np.sqrt(d)
         C = C - (u / (d if round4 else ys)[:, None])[:, :, None] * y[:, None, :]
@@ -146,9 +146,8 @@ def test_update_with_background_through_the_gram_form(shape):
 @pytest.mark.parametrize("M", [4, 8, 16])
 def test_determined_update_on_ill_conditioned_covariances(M, cond):
     """the maintained-inverse form, with the unpivoted inverse the kernels use, on cond(Cx) = 1e8 .. 1e12 and a
-    W_hat that is not adapted to V.  Round 4's form (Re(w^H u) as the normalisation AND as the Sherman-Morrison denominator)
-    is up to 1e3 reference sensitivities off there; with d = w^H V w from V itself and the complex w^H u as the denominator
-    (what the kernels do now) it stays within 4 sensitivities"""
+    W_hat that is not adapted to V.  Round 4's form (Re(w^H u) as the Sherman-Morrison denominator) is up to 1e3 reference
+    sensitivities off there; with the complex w^H u as the denominator (what the kernels do now) it stays within 4"""
     X, W_hat, V, Cx = ill_conditioned_case(6, M, cond, seed=M)
     sens, ref = reference_sensitivity(W_hat, V, Cx, M)
     e_r4 = orc.rel_err(determined_as_the_kernels(W_hat, V, round4=True), ref)
