@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // power_kernel<16, 2>, whose loads are 2 KB runs (lane = bin), moves the same bytes at 0.74.  Here the loads are those 2 KB
 // runs -- one frame's 16 bins x 16 channels, by LDS-DMA, no staging registers -- and the matrix cores read their frame-major
 // operands back from LDS:
-//   workgroup = one 64-bin batch x kPlFrames frames; 16 steps = 4 sub-batches of 16 bins x 4 tiles of 16 frames;
+//   workgroup = one 64-bin batch x kPlFrames frames; steps = 4 sub-batches of 16 bins x kPlTiles tiles of 16 frames;
 //   a step: 16 rows of 2 KB -> LDS (pitch 2 KB + 16 bytes: lane (frame j, quarter q) reads 32 bytes at row j -- the 16 frames
 //   of a read pass fall into 16 different bank groups); wave w multiplies bins 4w .. 4w + 3 of the sub-batch (W of its four
 //   bins in registers for the sub-batch's four steps); two buffers, the DMA of step s + 1 in flight behind the products of s;
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPlTiles = 4;                          // frame tiles of 16 per workgroup
 constexpr int kPlFrames = 16 * kPlTiles;
+constexpr int kPlSteps = 4 * kPlTiles;              // 4 sub-batches of 16 bins x the tiles
 constexpr int kPlRow = 16 * 16 * 8;                  // one frame's 16 bins x 16 channels
 constexpr int kPlPitch = kPlRow + 16;
 constexpr int kPlStage = 16 * kPlPitch;              // bytes per buffer
@@ -184,10 +185,10 @@ __global__ __launch_bounds__(kBlock, 2) void power_lds_kernel(const float2* __re
     const int t0 = blockIdx.y * kPlFrames;
     const size_t frame_stride = (size_t)F * M;       // float2 per frame
 
-    // step s = (sub-batch sb = s >> 2, tile tl = s & 3): rows = frames t0 + 16 tl + r, r < 16; this wave requests rows
+    // step s = (sub-batch sb = s / kPlTiles, tile tl = s % kPlTiles): rows = frames t0 + 16 tl + r, r < 16; this wave requests rows
     // 4 wave .. 4 wave + 3, each as two 1 KB halves (64 lanes x 16 bytes)
     auto issue = [&](int s, int buf) {
-        const int sb = s >> 2, tl = s & 3;
+        const int sb = s / kPlTiles, tl = s % kPlTiles;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int r = 4 * wave + rr;
@@ -220,12 +221,12 @@ __global__ __launch_bounds__(kBlock, 2) void power_lds_kernel(const float2* __re
             }
         static_for<kPlTiles>([&](auto tc) {
             constexpr int tl = decltype(tc)::value;
-            const int s = 4 * sb + tl;
+            const int s = kPlTiles * sb + tl;
             // buffer (s + 1) & 1 was read in step s - 1 and every wave has passed that step's second barrier
-            if (s + 1 < 16) issue(s + 1, (s + 1) & 1);
+            if (s + 1 < kPlSteps) issue(s + 1, (s + 1) & 1);
             // this wave's eight requests of step s have landed (those of s + 1 -- and nothing else -- may still be in flight),
             // then every wave's.  Raw barrier: __syncthreads() carries a release fence, which drains the DMA queue.
-            if (s + 1 < 16)
+            if (s + 1 < kPlSteps)
                 asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
