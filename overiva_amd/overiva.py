@@ -64,6 +64,8 @@ def release_cached_buffers():
     $OIVA_POOL_MB = 2048 MB) back to the driver"""
     from . import _lib
 
+    while _plan_cache:
+        _plan_cache.pop(next(iter(_plan_cache))).close()
     _lib.check(_lib.load().oiva_pool_trim())
 
 
@@ -203,9 +205,12 @@ def overiva(
         else:
             Y = solver.demix(proj_back, dtype)
         if return_filters:
-            return Y, solver.get_w().astype(dtype, copy=False)
+            W = solver.get_w().astype(dtype, copy=False)
+            solver.ok = True
+            return Y, W
         # surface a singular solve the way numpy.linalg.solve would (overiva.py:182)
         solver.get_w()
+        solver.ok = True
         return Y
     finally:
         solver.close()
@@ -226,6 +231,11 @@ def _prefault(a):
         pass
 
 
+# plans kept between calls (_SingleDevice.close), oldest first
+_plan_cache = {}
+_PLAN_CACHE_MAX = 0 if os.environ.get("OIVA_PLAN_CACHE", "1") == "0" else 2
+
+
 # (device, T, F, M, K) whose X-resident launch gave up in this process (its workgroups were not all co-resident: a shared or
 # CU-masked GPU): later calls of the same shape go straight to the four-launch path instead of waiting for the time-out again
 _resident_gave_up = set()
@@ -240,15 +250,21 @@ class _SingleDevice:
     GRAPH_MIN_ELEMENTS = 1 << 23
 
     def __init__(self, T, F, M, K, model, precision="fast"):
-        self.plan = Plan(T, F, M, K, model, device=get_device())
-        self.plan.set_precision(precision)
         self.wdtype = np.complex64 if precision == "fast" else np.complex128
         self.precision = precision
+        self.key = (get_device(), T, F, M, K)
+        # a plan of exactly this problem kept by an earlier call (see close()): its buffers, stream and captured graphs serve again
+        self.cache_key = self.key + (model, precision)
+        self.ok = False
+        self.plan = _plan_cache.pop(self.cache_key, None)
+        if self.plan is not None:
+            return
+        self.plan = Plan(T, F, M, K, model, device=get_device())
+        self.plan.set_precision(precision)
         if T * F * M >= self.GRAPH_MIN_ELEMENTS:
             self.plan.use_graph(True)
         # the loop body as one persistent launch with X on chip wherever the shape qualifies (csrc/resident_kernel.inc; the
         # float64 covariance of `precise` exists there for 4 channels); $OIVA_RESIDENT=0 keeps the four-launch path
-        self.key = (get_device(), T, F, M, K)
         if ((precision != "precise" or M == 4) and os.environ.get("OIVA_RESIDENT", "1") != "0" and self.key not in _resident_gave_up
                 and self.plan.resident_info()["qualifies"]):
             self.plan.set_resident(True)
@@ -285,4 +301,16 @@ class _SingleDevice:
                 _resident_gave_up.add(self.key)
             _last_info = {"precision": self.precision, "sharded": False, "resident_launches": info["launches"],
                           "resident_fallbacks": info["fallbacks"], "resident_give_up_code": info["last_give_up_code"]}
+            # A large plan of the four-launch path is kept for the next call of the same problem instead of being destroyed:
+            # creating and destroying it (streams, events, ~20 device buffers, captured graphs) is 2 ms of a 21 ms call at
+            # the headline shape.  At most _PLAN_CACHE_MAX plans, only after a call that ended normally;
+            # release_cached_buffers() destroys them ($OIVA_PLAN_CACHE=0: never kept).
+            T, F, M = self.key[1:4]
+            if (self.ok and not info["enabled"] and T * F * M >= self.GRAPH_MIN_ELEMENTS and _PLAN_CACHE_MAX > 0):
+                self.plan._keep = None              # (a borrowed device X of the caller is not held on to)
+                while len(_plan_cache) >= _PLAN_CACHE_MAX:
+                    _plan_cache.pop(next(iter(_plan_cache))).close()
+                _plan_cache[self.cache_key] = self.plan
+                self.plan = None
+                return
         self.plan.close()

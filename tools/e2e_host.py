@@ -18,13 +18,15 @@ for it in range(3):
     W = p.get_w(); p.close(); t6 = time.perf_counter()
     print(f"run {it}: create {1e3*(t1-t0):.1f} ms | upload X {1e3*(t2-t1):.1f} ms ({X.nbytes/1e9/(t2-t1):.1f} GB/s) | prologue {1e3*(t3-t2):.1f} | "
           f"20 its {1e3*(t4-t3):.1f} | demix+download Y {1e3*(t5-t4):.1f} ms ({Y.nbytes/1e9/(t5-t4):.1f} GB/s) | W+close {1e3*(t6-t5):.1f} | total {1e3*(t6-t0):.1f} ms")
-for _ in range(3):
-    t0 = time.perf_counter(); Y = oa.overiva(X, n_src=K, n_iter=20); print(f"overiva() 20 its end to end: {1e3*(time.perf_counter()-t0):.1f} ms")
+del Y
+# (the result of the previous call is dropped OUTSIDE the timed region: unmapping 131 MB is the caller's 3-5 ms, whoever made the array)
+for _ in range(4):
+    t0 = time.perf_counter(); Y = oa.overiva(X, n_src=K, n_iter=20); t1 = time.perf_counter(); print(f"overiva() 20 its end to end: {1e3*(t1-t0):.1f} ms"); del Y
 for dt in (np.complex64, np.complex128):
     Xd = X.astype(dt)
     for mode in ("precise", "fast"):
         oa.set_precision(mode)
         ts = []
         for _ in range(3):
-            t0 = time.perf_counter(); Y = oa.overiva(Xd, n_src=K, n_iter=20); ts.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); Y = oa.overiva(Xd, n_src=K, n_iter=20); ts.append(time.perf_counter() - t0); del Y
         print(f"overiva({np.dtype(dt).name}, {mode}) 20 its end to end: {' '.join(f'{1e3*t:.1f}' for t in ts)} ms")
