@@ -8,7 +8,9 @@ from oracle import overiva_oracle as orc
 T, F, M, K = 4000, 2048, 8, 2
 print("OIVA_DEMIX_IO =", os.environ.get("OIVA_DEMIX_IO", "(default)"), " OIVA_IO_THREADS =", os.environ.get("OIVA_IO_THREADS", "(default)"))
 X = orc.synth_iid(T, F, M, seed=0)
+Y = None
 for it in range(3):
+    del Y           # (unmapping the previous 131 MB result is not part of any stage below)
     t0 = time.perf_counter()
     p = oa.Plan(T, F, M, K, "laplace"); t1 = time.perf_counter()
     p.set_x(X); t2 = time.perf_counter()

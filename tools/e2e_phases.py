@@ -48,3 +48,48 @@ for rep in range(4):
     t0 = time.perf_counter(); Y = oa.overiva(X, n_src=K, n_iter=20); t1 = time.perf_counter()
     print(f"overiva() 20 its end to end: {ms(t1 - t0)} ms")
     del Y
+
+# complex128 in and out (what the reference's own drivers pass, overiva_oneshot.py:293): phases
+X128 = X.astype(np.complex128)
+for rep in range(3):
+    t = [time.perf_counter()]
+    p = oa.Plan(T, F, M, K, "laplace"); p.set_precision("precise"); p.use_graph(True); t.append(time.perf_counter())
+    p.set_x(X128); t.append(time.perf_counter())
+    p.covariance(); p.set_w(None); p.iterate(20); t.append(time.perf_counter())
+    out = np.empty((T, F, K), np.complex128); prefault(out); t.append(time.perf_counter())
+    p.sync(); t.append(time.perf_counter())
+    p.demix(True, out=out); t.append(time.perf_counter())
+    W = p.get_w(np.complex128); p.close(); t.append(time.perf_counter())
+    d = np.diff(t)
+    print(f"complex128: create {ms(d[0])} | upload + conversion of {X128.nbytes >> 20} MB {ms(d[1])} ({X128.nbytes / 1e9 / d[1]:.1f} GB/s) | queue prologue + 20 its {ms(d[2])} | "
+          f"alloc + pre-fault of {out.nbytes >> 20} MB {ms(d[3])} | wait for the iterations {ms(d[4])} | demix + hand-over {ms(d[5])} ({out.nbytes / 1e9 / d[5]:.1f} GB/s) | "
+          f"get_w + close {ms(d[6])} | total {ms(t[-1] - t[0])} ms", flush=True)
+    del out
+for rep in range(3):
+    t0 = time.perf_counter(); Y = oa.overiva(X128, n_src=K, n_iter=20); t1 = time.perf_counter()
+    print(f"overiva(complex128) 20 its end to end: {ms(t1 - t0)} ms")
+    del Y
+
+# complex64 input in the `precise` arithmetic (not the default for this dtype): phases, then the drop-in call
+for rep in range(4):
+    t = [time.perf_counter()]
+    p = oa.Plan(T, F, M, K, "laplace"); t.append(time.perf_counter())
+    p.set_precision("precise"); t.append(time.perf_counter())
+    p.use_graph(True); t.append(time.perf_counter())
+    p.set_x(X); t.append(time.perf_counter())
+    p.covariance(); p.sync(); t.append(time.perf_counter())
+    p.set_w(None); p.sync(); t.append(time.perf_counter())
+    p.iterate(20); t.append(time.perf_counter())
+    p.sync(); t.append(time.perf_counter())
+    out = np.empty((T, F, K), np.complex64); p.demix(True, out=out); t.append(time.perf_counter())
+    W = p.get_w(np.complex128); t.append(time.perf_counter())
+    p.close(); t.append(time.perf_counter())
+    print("complex64 precise: " + " | ".join(f"{n} {ms(x)}" for n, x in zip(("create", "set_precision", "use_graph", "upload", "covariance", "set_w", "queue 20 its", "wait", "demix", "get_w", "close"), np.diff(t)))
+          + f" | total {ms(t[-1] - t[0])} ms", flush=True)
+    del out
+oa.set_precision("precise")
+for rep in range(5):
+    t0 = time.perf_counter(); Y = oa.overiva(X, n_src=K, n_iter=20); t1 = time.perf_counter()
+    print(f"overiva(complex64, precise) 20 its end to end: {ms(t1 - t0)} ms")
+    del Y
+oa.set_precision("auto")
