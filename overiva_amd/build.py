@@ -38,9 +38,15 @@ def _stale(target, deps):
 # registers and 128 floats of X in the accumulator file: with the scheduler's default register-pressure model they end
 # in scratch memory (40-450 bytes per lane), with the more exact trackers they do not.  The resource remarks of these
 # files are kept next to the objects (tests/test_host.py checks that no resident kernel uses scratch).
-_RESIDENT = ("-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-Rpass-analysis=kernel-resource-usage")
+_REMARKS = ("-Rpass-analysis=kernel-resource-usage",)
+_RESIDENT = ("-mllvm", "-amdgpu-use-amdgpu-trackers=1") + _REMARKS
 EXTRA_FLAGS = {"kernels_resident_m8.hip": _RESIDENT, "kernels_resident_m4.hip": _RESIDENT, "kernels_resident_m6.hip": _RESIDENT,
                "kernels_resident_m2.hip": _RESIDENT}
+# every file that holds kernels leaves its resource remarks next to its object: tests/test_host.py checks that no kernel of the
+# iteration spills to scratch memory (round 5: a select of an (re, im) pair put 80 bytes per lane of update_det16_kernel there)
+for _src in SOURCES:
+    if _src.startswith("kernels_") or _src == "stft.hip":
+        EXTRA_FLAGS.setdefault(_src, _REMARKS)
 
 
 def _compile(src, extra=()):
@@ -80,10 +86,17 @@ def _compile(src, extra=()):
 
 def resident_kernel_usage():
     """{kernel name: {"vgprs", "agprs", "scratch"}} of the X-resident kernels, from the remarks of the last build"""
+    return kernel_usage(("kernels_resident_m4", "kernels_resident_m8", "kernels_resident_m6", "kernels_resident_m2"))
+
+
+def kernel_usage(sources=None):
+    """{kernel name: {"vgprs", "agprs", "scratch"}} of the kernels of the given sources (default: all that leave remarks)"""
     import re
 
+    if sources is None:
+        sources = [os.path.splitext(s)[0] for s in SOURCES if "-Rpass-analysis=kernel-resource-usage" in EXTRA_FLAGS.get(s, ())]
     out = {}
-    for src in ("kernels_resident_m4", "kernels_resident_m8", "kernels_resident_m6", "kernels_resident_m2"):
+    for src in sources:
         path = os.path.join(OBJ, src + ".usage.txt")
         if not os.path.exists(path):
             continue

@@ -626,8 +626,10 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
         // q == sq in element se
         wave_lds_sync();
         if (lane == sq) {
-            const C2<R> v = se == 0 ? y[0] : (se == 1 ? y[1] : (se == 2 ? y[2] : y[3]));
-            s.ppiv = v;
+            // (component-wise: a select of an (re, im) pair is compiled into a stack array indexed by the lane)
+            const R vre = se == 0 ? y[0].re : (se == 1 ? y[1].re : (se == 2 ? y[2].re : y[3].re));
+            const R vim = se == 0 ? y[0].im : (se == 1 ? y[1].im : (se == 2 ? y[2].im : y[3].im));
+            s.ppiv = {vre, vim};
         }
         wave_lds_sync();
         const C2<R> ys = s.ppiv;

@@ -167,3 +167,17 @@ def test_resident_kernels_use_no_scratch_memory(lib):
         assert u["vgprs"] + u["agprs"] <= 512
     # the variants that keep 8 frames per lane in registers need the accumulator file for them
     assert any(u["agprs"] >= 128 for name, u in usage.items() if "ILi8ELi2ELi8E" in name)
+
+
+def test_no_kernel_of_the_iteration_uses_scratch_memory():
+    """every kernel file leaves its compiler resource remarks next to its object (overiva_amd/build.py): no kernel on the path of
+    an iteration, the prologue or the epilogue may spill registers or index a lane-private array dynamically (either ends in
+    scratch memory = HBM traffic per lane).  Known exceptions: the one-time OGIVE initialisation kernels (per-thread matrices)."""
+    from overiva_amd import build
+
+    usage = build.kernel_usage()
+    if len(usage) < 100:
+        pytest.skip("resource remarks not available (library built without them)")
+    allowed = ("ogive_init_kernel", "ogive_switch_kernel")
+    bad = {n: u["scratch"] for n, u in usage.items() if u.get("scratch", 0) > 0 and not any(a in n for a in allowed)}
+    assert not bad, bad
