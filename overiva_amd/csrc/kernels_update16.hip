@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64) void update_wave16_kernel(UpdateArgs a) {
 //   C' = C - (u / d) (y - sqrt(d) e_s^T),   y = w^H C,   d = y_s = w^H u = w^H V_s w   (overiva.py:185)
 // and V_s^-1 by an elimination without pivot search (Hermitian positive definite) and without the product W_hat^H V_s.
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename VT>
+template <typename VT, bool INVERSE>   // INVERSE: w = V^-1 u through the explicit inverse (round 4; $OIVA_DET16_INVERSE=1), else one elimination on [V | u]
 __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
     using R = double;
     __shared__ LdsDet<R> s;
@@ -554,6 +554,58 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
 #undef OIVA_H16_STEP
     };
 
+    // ---- A x = rhs for a Hermitian positive definite A (identity outside M x M): Gauss-Jordan without pivot search on [A | rhs],
+    //      columns that are already eliminated skipped (known at compile time in the unrolled loop) -- 36 element updates per lane
+    //      instead of the 64 of the in-place inverse, and no product with the inverse afterwards.  rhs: one value per row (equal
+    //      within the quad); returns x the same way.
+    auto solve_hpd = [&](C2<R> (&A)[4], C2<R> rhs) -> C2<R> {
+        R piv = R(1);
+        auto step = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int ke = k >> 2, kq = k & 3;
+            constexpr int e0 = (k + 1) >> 2;               // elements below e0 hold only eliminated columns
+            const C2<R> aik = quad_bcast<kq>(A[ke]);       // A[i][k]
+            wave_lds_sync();
+            if (i == k) {
+#pragma unroll
+                for (int e = e0; e < 4; ++e) s.prow[q][e] = A[e];
+                if (q == 0) {
+                    s.ppiv = aik;                          // A[k][k] (real: Schur complements stay Hermitian)
+                    s.prhs = rhs;
+                }
+            }
+            wave_lds_sync();
+            const R pr = s.ppiv.re;
+            R d = __builtin_amdgcn_rcp(pr);
+            d = fma(fma(-pr, d, 1.0), d, d);
+            d = fma(fma(-pr, d, 1.0), d, d);
+            const bool rowk = i == k;
+            piv = rowk ? pr : piv;
+            const C2<R> fct = {rowk ? R(0) : aik.re * d, rowk ? R(0) : aik.im * d};      // the pivot row eliminates with factor 0
+#pragma unroll
+            for (int e = e0; e < 4; ++e) {
+                const C2<R> r = s.prow[q][e];
+                A[e].re -= fct.re * r.re - fct.im * r.im;
+                A[e].im -= fct.re * r.im + fct.im * r.re;
+            }
+            const C2<R> bp = s.prhs;
+            rhs.re -= fct.re * bp.re - fct.im * bp.im;
+            rhs.im -= fct.re * bp.im + fct.im * bp.re;
+        };
+#define OIVA_S16_STEP(c) \
+    if (c < M) step(std::integral_constant<int, c>{});
+        OIVA_S16_STEP(0) OIVA_S16_STEP(1) OIVA_S16_STEP(2) OIVA_S16_STEP(3) OIVA_S16_STEP(4) OIVA_S16_STEP(5) OIVA_S16_STEP(6)
+        OIVA_S16_STEP(7) OIVA_S16_STEP(8) OIVA_S16_STEP(9) OIVA_S16_STEP(10) OIVA_S16_STEP(11) OIVA_S16_STEP(12)
+        OIVA_S16_STEP(13) OIVA_S16_STEP(14) OIVA_S16_STEP(15)
+#undef OIVA_S16_STEP
+        // x_i = rhs_i / (the pivot of row i, kept when the row pivoted: entries of eliminated columns are not zeroed, so the
+        // diagonal itself is stale by now)
+        R d = __builtin_amdgcn_rcp(piv);
+        d = fma(fma(-piv, d, 1.0), d, d);
+        d = fma(fma(-piv, d, 1.0), d, d);
+        return {rhs.re * d, rhs.im * d};
+    };
+
     const R invT = R(1) / R(a.T);
     for (int src = 0; src < M; ++src) {
         double acc[4] = {0., 0., 0., 0.};
@@ -583,8 +635,7 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
                 if (sgn[e] != 0.f) Vi[e].im = s.pk[off[e] + 1] * R(sgn[e]) * invT;
             }
         }
-        herm_inverse(Vi);
-        // u = column src of C: u_i for the row, u_c for the lane's four columns (through LDS)
+        // u = column src of C: u_i for the row (through LDS)
         const int se = src >> 2, sq = src & 3;
         wave_lds_sync();
         if (q == sq) {
@@ -595,25 +646,24 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
         }
         wave_lds_sync();
         const C2<R> ui = s.w[i];
-        // row i of (matrix held four columns per lane) x (vector by index in LDS), on every lane of the quad
-        auto matvec = [&](const C2<R> (&A)[4], const C2<R> (&x)[N]) -> C2<R> {
-            R vr = R(0), vi = R(0);
+        // w = V^-1 u (not yet normalised)
+        C2<R> wi;
+        if constexpr (INVERSE) {
+            herm_inverse(Vi);
+            R wr = R(0), wim = R(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const C2<R> xc = x[4 * e + q];
-                vr += A[e].re * xc.re - A[e].im * xc.im;
-                vi += A[e].re * xc.im + A[e].im * xc.re;
+                const C2<R> uc = s.w[4 * e + q];
+                wr += Vi[e].re * uc.re - Vi[e].im * uc.im;
+                wim += Vi[e].re * uc.im + Vi[e].im * uc.re;
             }
-            return {quad_sum(vr), quad_sum(vi)};
-        };
-        auto publish = [&](C2<R> (&x)[N], C2<R> v) {             // x[i] = v (equal within the quad)
-            wave_lds_sync();
-            if (q == 0) x[i] = v;
-            wave_lds_sync();
-        };
-        // w = V^-1 u (not yet normalised)
-        const C2<R> wi = matvec(Vi, s.w);
-        publish(s.w, wi);
+            wi = {quad_sum(wr), quad_sum(wim)};
+        } else {
+            wi = solve_hpd(Vi, ui);
+        }
+        wave_lds_sync();
+        if (q == 0) s.w[i] = wi;
+        wave_lds_sync();
         // y = w^H C: column sums over the 16 rows (lanes of equal q)
         C2<R> y[4];
 #pragma unroll
@@ -667,10 +717,12 @@ hipError_t launch_update_wave16(hipStream_t s, const UpdateArgs& a) {
     const bool over = a.K < a.M;
     static const bool det = [] { const char* v = getenv("OIVA_UPDATE_DET"); return !(v && v[0] == '0'); }();
     if (det && !over && a.use_double && !a.init_only) {
-        if (a.vpart_f64)
-            go(update_det16_kernel<double>);
-        else
-            go(update_det16_kernel<float>);
+        static const bool inv = [] { const char* v = getenv("OIVA_DET16_INVERSE"); return v && v[0] == '1'; }();
+        if (a.vpart_f64) {
+            if (inv) go(update_det16_kernel<double, true>); else go(update_det16_kernel<double, false>);
+        } else {
+            if (inv) go(update_det16_kernel<float, true>); else go(update_det16_kernel<float, false>);
+        }
         return hipGetLastError();
     }
 #define OIVA_GO(RR, VV)                                         \

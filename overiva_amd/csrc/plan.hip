@@ -1170,7 +1170,13 @@ static int demix_to_host(oiva_plan* p, void* Y_host, long long row_pitch_bytes, 
         registered = hipHostRegister(Y_host, pitch * (size_t)(p->T - 1) + row, hipHostRegisterDefault) == hipSuccess;
         if (!registered) (void)hipGetLastError();      // (an unaligned or foreign range: the ring serves)
     }
-    if (!registered) HIP_TRY(host_ring_slots(slab_bytes, pinned));
+    // (the pinned ring and the copy threads are process-wide: one hand-over at a time, whatever thread or plan asks)
+    static std::mutex io_mutex;
+    std::unique_lock<std::mutex> io_lock(io_mutex, std::defer_lock);
+    if (!registered) {
+        io_lock.lock();
+        HIP_TRY(host_ring_slots(slab_bytes, pinned));
+    }
     auto finish = [&](hipError_t e) -> int {
         if (registered) {
             (void)hipStreamSynchronize(p->io_stream);
