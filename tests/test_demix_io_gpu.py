@@ -80,3 +80,44 @@ def test_every_form_of_the_hand_over_in_the_drop_in_call(mode, tmp_path):
     for k in ("Y64", "Y128", "W"):
         assert np.array_equal(outs[mode][k], outs["legacy"][k]), k
     assert outs[mode]["Y128"].dtype == np.complex128
+
+
+def test_a_plan_kept_between_calls_gives_the_results_of_a_fresh_one(oa):
+    """overiva() keeps large plans of the four-launch path for the next call of the same problem (overiva.py::_plan_cache) and
+    the library pools their big device buffers: a second call on OTHER data, a warm start, a callback run and the other model
+    must give the bits of calls on fresh plans, and release_cached_buffers() must hand the memory back"""
+    import torch
+
+    from overiva_amd import overiva as ov
+
+    T, F, M, K = 1100, 1000, 8, 2                    # 8.8 M elements: above the caching threshold, four-launch path
+    X1, X2 = orc.synth_mixture(T, F, M, K, seed=1), orc.synth_iid(T, F, M, seed=2)
+    rng = np.random.default_rng(0)
+    W0 = (np.eye(M, K)[None] + 0.1 * (rng.standard_normal((F, M, K)) + 1j * rng.standard_normal((F, M, K)))).astype(np.complex64)
+
+    def calls():
+        seen = []
+        out = [oa.overiva(X1, n_src=K, n_iter=4),
+               oa.overiva(X2, n_src=K, n_iter=3, proj_back=False, return_filters=True),
+               oa.overiva(X1, n_src=K, n_iter=12, W0=W0, callback=lambda y: seen.append(y.copy())),
+               oa.overiva(X2, n_src=K, n_iter=2, model="gauss")]
+        return out, seen
+
+    oa.release_cached_buffers()
+    os.environ["OIVA_PLAN_CACHE"] = "1"
+    a, seen_a = calls()
+    assert len(ov._plan_cache) >= 1                   # something was kept
+    a2, _ = calls()                                   # every call now starts from a kept plan
+    free_held = torch.cuda.mem_get_info()[0]
+    oa.release_cached_buffers()
+    assert not ov._plan_cache and torch.cuda.mem_get_info()[0] > free_held + (64 << 20)
+    keep, ov._PLAN_CACHE_MAX = ov._PLAN_CACHE_MAX, 0  # fresh plans
+    try:
+        b, seen_b = calls()
+    finally:
+        ov._PLAN_CACHE_MAX = keep
+        oa.release_cached_buffers()
+    flat = lambda r: [x for y in r for x in (y if isinstance(y, tuple) else (y,))]
+    for x, y, z in zip(flat(a), flat(a2), flat(b)):
+        assert np.array_equal(x, z) and np.array_equal(y, z)
+    assert len(seen_a) == len(seen_b) == 2 and all(np.array_equal(p, q) for p, q in zip(seen_a, seen_b))

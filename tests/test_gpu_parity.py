@@ -319,7 +319,8 @@ def test_overiva_matches_reference(oa, golden, model, n_iter, dt):
     if mode == "mixed" and floor is not None:
         b128 = max(b128, yard)   # never less accurate than the reference's own complex64 arithmetic
     _log(test="e2e", fixture=golden["_id"], model=model, n_iter=n_iter, input=dt, mode=mode, W_vs_c128=e128,
-         Y_vs_c128=eY, W_vs_ref_c64=e64, ref_c64_floor=floor, amp=_amp(golden, model, n_iter), bound_c128=b128)
+         Y_vs_c128=eY, W_vs_ref_c64=e64, ref_c64_floor=floor, amp=_amp(golden, model, n_iter), bound_c128=b128,
+         ref_c64_jitter=c64_jitter(golden, model, n_iter))
     print(f"\n[parity] {golden['_id']} {model} n_iter={n_iter} {dt} ({mode}): W vs c128 {e128:.2e} (bound {b128:.1e}), Y {eY:.2e}"
           + (f", W vs reference-c64 {e64:.2e} (floor {floor:.1e})" if floor is not None else ""))
     assert e128 < b128 and eY < b128

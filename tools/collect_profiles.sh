@@ -70,6 +70,10 @@ python3 $ROOT/tools/exp_resident_trace.py 4000 256 8 2 20 mixed > "$OUT/resident
 python3 $ROOT/tools/exp_resident_trace.py 4000 256 8 2 20 mixed 8 > "$OUT/resident_trace_shard8_loopback8.log" 2>&1
 python3 $ROOT/tools/res_ab.py > "$OUT/resident_configs.log" 2>&1
 python3 $ROOT/tools/cfg5_cov_sweep.py > "$OUT/cfg5_cov_sweep.log" 2>&1
+# (round 5) the drop-in call with host arrays, end to end and phase by phase; the reference's sweep shapes stage by stage
+python3 $ROOT/tools/e2e_phases.py > "$OUT/e2e_phases.log" 2>&1
+python3 $ROOT/tools/e2e_host.py > "$OUT/e2e_host.log" 2>&1
+python3 $ROOT/tools/stage_times_reference_shapes.py > "$OUT/stage_times_reference_shapes.log" 2>&1
 # keep what travels back small: drop the raw kernel traces of the --stats runs
 find "$OUT" -name "*_kernel_trace.csv" -path "*stats_*" -delete
 find "$OUT" -name "*_agent_info.csv" -delete

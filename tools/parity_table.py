@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the JSON-lines log of tests/test_gpu_parity.py ($OIVA_PARITY_LOG) into the markdown table committed
-under profiles/.   python tools/parity_table.py gpurun_out/parity.jsonl > profiles/r04_parity_errors.md"""
+under profiles/.   python tools/parity_table.py gpurun_out/parity.jsonl > profiles/r05_parity_errors.md"""
 import json
 import sys
 
@@ -11,7 +11,7 @@ def f(x):
 
 rows = [json.loads(line) for line in open(sys.argv[1])]
 e2e = [r for r in rows if r["test"] == "e2e"]
-print("# Achieved parity errors (MI355X, round 4)\n")
+print("# Achieved parity errors (MI355X, round 5)\n")
 print("Source: `tests/test_gpu_parity.py` run with `OIVA_PARITY_LOG` on the GPU box; distances are relative Frobenius")
 print("norms.  `floor` = distance between the REAL reference's complex64 and complex128 results on the fixture")
 print("(stored by `tests/golden/make_golden.py`); `amp` = the reference's own amplification of a 1e-12 input")
@@ -19,8 +19,10 @@ print("perturbation.  Default arithmetic (`auto`): complex64 input runs `mixed` 
 print("chains, float64 sums and per-bin algebra; the X-resident kernel where the shape qualifies); complex128 input runs")
 print("`precise`.  `fast` = float32 per-bin algebra too.\n")
 print("## overiva(), complex64 input (the default mode of that input), final W after n_iter iterations\n")
-print("| fixture | model | n_iter | amp | mode | reference c64 floor | W vs reference-c64 | in floors | W vs c128 | in floors | Y vs c128 | fast: W vs c128 | in floors |")
-print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+print("`jitter` = how far the reference's own complex64 W moves when X changes in its last bit (tests/golden/c64_jitter.npz); rows")
+print("whose jitter exceeds 1e-3 are held to max(floor, jitter) instead of the floor (marked *).\n")
+print("| fixture | model | n_iter | amp | mode | reference c64 floor | c64 jitter | W vs reference-c64 | in floors | W vs c128 | in floors | Y vs c128 | fast: W vs c128 | in floors |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 key = lambda r: (r["fixture"], r["model"], r["n_iter"])
 dflt = {key(r): r for r in e2e if r["input"] == "c64" and r["mode"] in ("mixed", "precise")}
 fast = {key(r): r for r in e2e if r["mode"] == "fast"}
@@ -33,7 +35,8 @@ for k in sorted(dflt):
     if fl and fl > 2e-7:
         w = worst.setdefault(p["mode"], [0.0, 0.0])
         w[0], w[1] = max(w[0], r64), max(w[1], r128)
-    print(f"| {k[0]} | {k[1]} | {k[2]} | {p['amp']:.1f} | {p['mode']} | {f(fl)} | {f(p.get('W_vs_ref_c64'))} | {r64:.2f} | {f(p['W_vs_c128'])} | {r128:.2f} | "
+    jit = p.get("ref_c64_jitter")
+    print(f"| {k[0]} | {k[1]} | {k[2]} | {p['amp']:.1f} | {p['mode']} | {f(fl)} | {f(jit)}{'*' if jit and jit > 1e-3 else ''} | {f(p.get('W_vs_ref_c64'))} | {r64:.2f} | {f(p['W_vs_c128'])} | {r128:.2f} | "
           f"{f(p.get('Y_vs_c128'))} | {f(q['W_vs_c128']) if q else '-'} | {(q['W_vs_c128'] / fl if q and fl else float('nan')):.1f} |")
 print("\nWorst ratios where the floor exceeds 2e-7 (distance to the reference's complex64 result / to its complex128 result, in floors): "
       + "; ".join(f"{m}: {w[0]:.2f} / {w[1]:.2f}" for m, w in sorted(worst.items())))
