@@ -94,9 +94,9 @@ def cov_algorithmic_bytes(t, f, m, k):
 def measured_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same workload
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction; see
-    profiles/r03_pmc_hbm_traffic.json).  PMC counters need rocprofv3 around the process, so they cannot
+    profiles/r05_pmc_hbm_traffic.json).  PMC counters need rocprofv3 around the process, so they cannot
     be sampled from inside a plain bench run; None when the profile is absent."""
-    for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+    for name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json"):
         path = os.path.join(REPO, "profiles", name)
         try:
             with open(path) as f:

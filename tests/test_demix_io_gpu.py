@@ -88,7 +88,7 @@ def test_a_plan_kept_between_calls_gives_the_results_of_a_fresh_one(oa):
     must give the bits of calls on fresh plans, and release_cached_buffers() must hand the memory back"""
     import torch
 
-    from overiva_amd import overiva as ov
+    ov = sys.modules["overiva_amd.overiva"]          # (the package attribute `overiva` is the function, not the module)
 
     T, F, M, K = 1100, 1000, 8, 2                    # 8.8 M elements: above the caching threshold, four-launch path
     X1, X2 = orc.synth_mixture(T, F, M, K, seed=1), orc.synth_iid(T, F, M, seed=2)
