@@ -121,3 +121,34 @@ def test_a_plan_kept_between_calls_gives_the_results_of_a_fresh_one(oa):
     for x, y, z in zip(flat(a), flat(a2), flat(b)):
         assert np.array_equal(x, z) and np.array_equal(y, z)
     assert len(seen_a) == len(seen_b) == 2 and all(np.array_equal(p, q) for p, q in zip(seen_a, seen_b))
+
+
+def test_graph_cache_eviction_pool_trim_and_replanning_keep_the_results(oa):
+    """one plan driven through more graph lengths than its cache holds (6), a trim of the buffer pool in the middle, a new X on
+    the same plan and a precision switch: every state it passes through equals that of a plan driven eagerly"""
+    T, F, M, K = 300, 200, 4, 2
+    X1, X2 = orc.synth_iid(T, F, M, seed=5), orc.synth_mixture(T, F, M, K, seed=6)
+    chunks = [1, 2, 3, 5, 7, 11, 13, 2, 40, 1]          # 9 distinct lengths (40 = 32 + 8)
+
+    def run(graph):
+        out = []
+        with oa.Plan(T, F, M, K, "laplace") as p:
+            p.set_precision("mixed")
+            p.use_graph(graph)
+            for X in (X1, X2):
+                p.set_x(X)
+                p.covariance()
+                p.set_w(None)
+                for i, n in enumerate(chunks):
+                    p.iterate(n)
+                    if i == 4:
+                        oa.release_cached_buffers()
+                out.append(p.get_w(np.complex128))
+                out.append(p.demix(True))
+            p.set_precision("fast")
+            p.iterate(3)
+            out.append(p.get_w())
+        return out
+
+    for a, b in zip(run(False), run(True)):
+        assert np.array_equal(a, b)
