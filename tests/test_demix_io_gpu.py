@@ -90,7 +90,7 @@ def test_a_plan_kept_between_calls_gives_the_results_of_a_fresh_one(oa):
 
     ov = sys.modules["overiva_amd.overiva"]          # (the package attribute `overiva` is the function, not the module)
 
-    T, F, M, K = 1100, 1000, 8, 2                    # 8.8 M elements: above the caching threshold, four-launch path
+    T, F, M, K = 1100, 1000, 8, 3                    # 8.8 M elements: above the caching threshold; 3 sources: four-launch path
     X1, X2 = orc.synth_mixture(T, F, M, K, seed=1), orc.synth_iid(T, F, M, seed=2)
     rng = np.random.default_rng(0)
     W0 = (np.eye(M, K)[None] + 0.1 * (rng.standard_normal((F, M, K)) + 1j * rng.standard_normal((F, M, K)))).astype(np.complex64)
