@@ -221,8 +221,22 @@ def _make_plan(oa, X, shape, mode, graph, resident=False):
     return plan
 
 
-def _cov_roofline(shape, mode, cov_ms):
+def _cov_roofline(shape, mode, cov_ms, fused=False):
     t, f, m, k = shape
+    if m <= 8 and fused:
+        # covariance + per-bin update of the same bins in ONE launch (csrc/kernels_cov_update.hip): the float64 partials stay in
+        # LDS -- the 8 F K M^2 bytes SURVEY 8d counts for V are not written -- and W_hat (complex64 + complex128) and Cx are read,
+        # W_hat written: 8 T F M + 4 T K + F M^2 (8 + 16 + 8 + 8 + 16)
+        bytes_cov = 8 * t * f * m + 4 * t * k + f * m * m * 56
+        achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
+        kname = "cov_update_kernel<double>" if mode != "fast" else "cov_update_kernel<float>"
+        return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass AND the per-bin IP1 solve / normalisation / "
+                                                 "orthogonal-constraint update of the same bins in one launch, overiva.py:158-190)",
+                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
+                       "note": "the launch ends with the latency-bound per-bin chain of its four bins per workgroup (5-6 us during which "
+                               "nothing streams); the covariance kernel it replaces (cov_dma_kernel<8, 2>, $OIVA_COV_UPDATE=0) takes 97-99 us "
+                               "for 526.4 MB = 0.67 of the peak and is followed by update_bg_kernel (12.8 us)"}
     if m <= 8:
         bytes_cov = cov_algorithmic_bytes(t, f, m, k)
         achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
@@ -371,9 +385,10 @@ def _secondary_config(torch, oa, dev, name, args):
     plan = _make_plan(oa, X, shape, mode, True)
     dt, total_ms, stages, more = _time_plan(plan, args, repeats=args.repeats)
     info = plan.resident_info()
+    one_launch = plan.set_fuse_cov_update(None)
     plan.close()
     cov_ms = stages["weighted_cov"] / args.steps
-    _, roof = _cov_roofline(shape, mode, cov_ms)
+    _, roof = _cov_roofline(shape, mode, cov_ms, one_launch)
     if name in ("cfg2", "cfg0"):
         roof["note"] = "16 MB of X: resident in L2 / Infinity Cache, the pass is launch- and latency-bound, not a roofline claim"
     out["four_launch"] = {"value": args.steps / dt, "unit": "iterations/s", "ms_per_step": dt / args.steps * 1e3, **_rates(args.steps, [dt] + more),
@@ -459,9 +474,10 @@ def run_single(args):
                 continue
             plan = _make_plan(oa, X, shape, other, args.graph)
             dt2, total2, stages2, more2 = _time_plan(plan, args, repeats=args.repeats)
+            one_launch2 = plan.set_fuse_cov_update(None)
             plan.close()
             cov2 = stages2["weighted_cov"] / args.steps
-            _, roof2 = _cov_roofline(shape, other, cov2)
+            _, roof2 = _cov_roofline(shape, other, cov2, one_launch2)
             other_modes.append({"precision": other, "value": args.steps / dt2, "unit": "iterations/s", "ms_per_step": dt2 / args.steps * 1e3,
                                 **_rates(args.steps, [dt2] + more2),
                                 "stage_ms_per_step": {k: v / args.steps for k, v in stages2.items()},
@@ -471,10 +487,11 @@ def run_single(args):
     W = plan.get_w()
     assert np.all(np.isfinite(W))
     splits = plan.cov_splits()
+    one_launch = plan.set_fuse_cov_update(None)
     plan.close()
     cov_ms = stages["weighted_cov"] / args.steps
     per_step = {k: v / args.steps for k, v in stages.items()}
-    kname, roofline = _cov_roofline(shape, args.precision, cov_ms)
+    kname, roofline = _cov_roofline(shape, args.precision, cov_ms, one_launch)
     if M <= 8:
         traffic, traffic_src = measured_traffic(kname)
         roofline.update({"traffic": traffic, "traffic_source": traffic_src})
@@ -748,6 +765,7 @@ def run_sharded(args):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     W = eng.get_w()
     assert np.all(np.isfinite(W))
+    one_launch = eng.plan.set_fuse_cov_update(None)
     exchange_name, exchange_fallback = xchg.name, getattr(xchg, "fallback_reason", None)
     xchg.close()
     eng.close()
@@ -764,7 +782,7 @@ def run_sharded(args):
         out["config"]["parallelism"] = (f"bins sharded over {world} GPU(s); X-resident persistent kernel per rank, the partial source powers "
                                         "exchanged inside it by peer stores over xGMI (no collective in the loop)")
     else:
-        _, roof = _cov_roofline((T, fl, M, K), args.precision, cov_ms)
+        _, roof = _cov_roofline((T, fl, M, K), args.precision, cov_ms, one_launch)
         roof["kernel"] += f" on rank 0's {fl} bins"
         roof["per"] = "GPU"
         roof.setdefault("traffic", None)

@@ -232,6 +232,11 @@ int oiva_plan_set_pow_splits(oiva_plan *p, int nsplit);
 /* 10..16 channels with 9..16 sources: the covariance pass with the sources on the fp32 matrix cores (default, csrc/kernels_cov_hmfma.hip)
  * or on the vector ALU alone (enable = 0; same bits: A/B tests). */
 int oiva_plan_set_cov_hmfma(oiva_plan *p, int enable);
+/* 8 channels, 2 sources + background, float32 covariance products, four frame splits (the headline shape): the weighted
+ * covariance (overiva.py:179) and the per-bin update of the same bins (:181-190) as ONE launch (csrc/kernels_cov_update.hip; same
+ * bits as the two launches; measured no faster, so off by default: $OIVA_COV_UPDATE=1 or enable = 1).  enable 1 / 0; -1 only
+ * asks.  *active: whether this plan's iterations run it. */
+int oiva_plan_set_fuse_cov_update(oiva_plan *p, int enable, int *active);
 /* Replay the iteration from a captured hipGraph instead of eager launches (default off). */
 int oiva_plan_use_graph(oiva_plan *p, int enable);
 /* Arithmetic: an OR of OIVA_PREC_* (default OIVA_PREC_FAST).  Call it before oiva_plan_covariance so that the

@@ -78,6 +78,7 @@ SIGNATURES = {
     "oiva_plan_set_cov_quad": [_vp, _i, C.POINTER(_i)],
     "oiva_plan_set_pow_splits": [_vp, _i],
     "oiva_plan_set_cov_hmfma": [_vp, _i],
+    "oiva_plan_set_fuse_cov_update": [_vp, _i, C.POINTER(_i)],
     "oiva_plan_use_graph": [_vp, _i],
     "oiva_plan_set_precision": [_vp, _i],
     "oiva_plan_set_resident": [_vp, _i],

@@ -236,6 +236,11 @@ __device__ __forceinline__ void sum_vpart(const void* base, int f64, size_t idx,
     if (!pair) si = 0.;
 }
 hipError_t launch_update(hipStream_t s, const UpdateArgs& a);
+// covariance + per-bin update of the same bins in ONE launch (kernels_cov_update.hip): 8 channels, 2 sources + background,
+// float32 products; frames in four splits of tc (one per wave of a 4-bin workgroup).  Same bits as launch_cov followed by
+// launch_update when the plan's covariance geometry is those four splits.  a: What, What64, Cx, T, F, use_double.
+bool cov_update_supported(int M, int K, int T, int F, int nsplit, int tc);
+hipError_t launch_cov_update(hipStream_t s, const float2* X, const float* R, float* wscale, int model, const UpdateArgs& a, int tc);
 hipError_t launch_update_wave16(hipStream_t s, const UpdateArgs& a);   // 9..16 channels, one wavefront per bin
 
 // Epilogue, overiva.py:192-199.

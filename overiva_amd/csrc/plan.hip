@@ -141,6 +141,7 @@ struct oiva_plan {
     CovGeom cov{};
     bool cov_quad_on = true;      // oiva_plan_set_cov_quad
     bool cov_hmfma_on = true;     // oiva_plan_set_cov_hmfma ($OIVA_COV_HMFMA=0: off)
+    bool fuse_cov_update = false; // oiva_plan_set_fuse_cov_update ($OIVA_COV_UPDATE=1: on wherever the shape qualifies)
     CovGeom stg{};              // geometry of the projection-back statistics pass (16-bin groups, independent of cov)
     PowGeom pw{};
     int n_cu = 256;
@@ -455,10 +456,36 @@ int stage_update(oiva_plan* p, bool init_only) {
     return OIVA_OK;
 }
 
+// covariance and per-bin update as one launch (kernels_cov_update.hip) where the plan's geometry is the kernel's: the headline
+// shape and its neighbours (8 channels, 2 sources, four frame splits)
+bool cov_update_applies(const oiva_plan* p) {
+    return p->fuse_cov_update && !p->cov_f64() && !p->cov.pair32 && !p->raw_weights && !(p->prec & OIVA_PREC_UPDATE_ROWS) && p->K < p->M &&
+           cov_update_supported(p->M, p->K, p->T, p->F, p->cov.nsplit, p->cov.tc);
+}
+int stage_cov_update(oiva_plan* p) {
+    UpdateArgs a;
+    a.What = p->What;
+    a.What64 = p->upd_f64() ? p->What64 : nullptr;
+    a.Cx = p->Cx;
+    a.Vpart = nullptr;
+    a.vpart_f64 = 1;
+    a.wscale = nullptr;
+    a.nsplit = p->cov.nsplit;
+    a.T = p->T, a.F = p->F, a.M = p->M, a.K = p->K;
+    a.init_only = 0;
+    a.use_double = p->upd_f64() ? 1 : 0;
+    a.layout = 0;
+    HIP_TRY(launch_cov_update(p->stream, p->X, p->R, p->wscale, p->model, a, p->cov.tc));
+    p->what64_valid = a.What64 != nullptr;
+    p->wscale_pending = false;
+    return OIVA_OK;
+}
+
 int one_iteration(oiva_plan* p) {
     int rc;
     if ((rc = stage_power(p))) return rc;
     if ((rc = stage_activation(p, p->Ppart, p->pw.nb))) return rc;
+    if (cov_update_applies(p)) return stage_cov_update(p);
     if ((rc = stage_cov(p))) return rc;
     return stage_update(p, false);
 }
@@ -763,6 +790,8 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     {
         const char* v = std::getenv("OIVA_COV_HMFMA");
         p->cov_hmfma_on = !(v && v[0] == '0');
+        const char* u = std::getenv("OIVA_COV_UPDATE");
+        p->fuse_cov_update = u && u[0] == '1';
     }
     choose_cov_geom(p, 0);
     choose_pow_geom(p, 0);
@@ -1085,6 +1114,7 @@ int oiva_plan_update(oiva_plan* p, const void* parts_dev, int nparts) {
     NEED(parts_dev && nparts >= 1, OIVA_ERR_ARG, "need at least one part");
     DeviceGuard guard(p->device);
     if ((rc = stage_activation(p, (const float*)parts_dev, nparts))) return rc;
+    if (cov_update_applies(p)) return stage_cov_update(p);
     if ((rc = stage_cov(p))) return rc;
     return stage_update(p, false);
 }
@@ -1470,13 +1500,14 @@ int oiva_plan_iterate_timed(oiva_plan* p, int n, float* total_ms, float* per_ker
         err = hipEventRecord(e[0], p->stream);
         if (err == hipSuccess && !(rc = stage_power(p))) err = hipEventRecord(e[1], p->stream);
         if (err == hipSuccess && !rc && !(rc = stage_activation(p, p->Ppart, p->pw.nb))) err = hipEventRecord(e[2], p->stream);
+        const bool fused = cov_update_applies(p);          // covariance + update as one launch: all of it is stage 2, stage 3 is empty
         if (err == hipSuccess && !rc) {
             arm_kernel_timer(kev[2 * it], kev[2 * it + 1]);    // the covariance kernel's own start / stop (see launch_dominant)
-            rc = stage_cov(p);
+            rc = fused ? stage_cov_update(p) : stage_cov(p);
             arm_kernel_timer(nullptr, nullptr);
             if (!rc) err = hipEventRecord(e[3], p->stream);
         }
-        if (err == hipSuccess && !rc && !(rc = stage_update(p, false))) err = hipEventRecord(e[4], p->stream);
+        if (err == hipSuccess && !rc && !(fused ? OIVA_OK : (rc = stage_update(p, false)))) err = hipEventRecord(e[4], p->stream);
     }
     if (err == hipSuccess && rc == OIVA_OK) err = hipStreamSynchronize(p->stream);
     for (int it = 0; it < n && err == hipSuccess && rc == OIVA_OK; ++it) {
@@ -1535,6 +1566,19 @@ int oiva_plan_set_cov_quad(oiva_plan* p, int enable, int* active) {
     choose_cov_geom(p, 0);
     if (active) *active = p->cov.quad || p->cov.half16;
     return ensure_vpart(p);
+}
+
+int oiva_plan_set_fuse_cov_update(oiva_plan* p, int enable, int* active) {
+    NEED(p, OIVA_ERR_ARG, "null plan");
+    DeviceGuard guard(p->device);
+    if (enable >= 0) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        int rc = drop_graph(p);
+        if (rc) return rc;
+        p->fuse_cov_update = enable != 0;
+    }
+    if (active) *active = cov_update_applies(p) ? 1 : 0;
+    return OIVA_OK;
 }
 
 int oiva_plan_set_cov_hmfma(oiva_plan* p, int enable) {
@@ -1965,8 +2009,8 @@ int oiva_test_time_stage(oiva_plan* p, int stage, int reps, float* avg_ms) {
         switch (stage) {
             case 0: return stage_power(p);
             case 1: return stage_activation(p, p->Ppart, p->pw.nb);
-            case 2: return stage_cov(p);
-            default: return stage_update(p, false);
+            case 2: return cov_update_applies(p) ? stage_cov_update(p) : stage_cov(p);      // (one launch for both where the plan runs it so)
+            default: return cov_update_applies(p) ? OIVA_OK : stage_update(p, false);
         }
     };
     if ((rc = run())) return rc;  // warm

@@ -232,6 +232,13 @@ class Plan:
         """9..16 sources on 10..16 channels: the sources on the fp32 matrix cores (default) or the vector-ALU kernel alone"""
         _lib.check(self.lib.oiva_plan_set_cov_hmfma(self.h, 1 if enable else 0))
 
+    def set_fuse_cov_update(self, enable=True):
+        """covariance + per-bin update as one launch where the shape qualifies (8 channels, 2 sources, four frame splits: the
+        headline shape); returns whether this plan's iterations run it.  ``enable=None`` only asks."""
+        a = C.c_int()
+        _lib.check(self.lib.oiva_plan_set_fuse_cov_update(self.h, -1 if enable is None else (1 if enable else 0), C.byref(a)))
+        return bool(a.value)
+
     def set_pow_splits(self, n):
         _lib.check(self.lib.oiva_plan_set_pow_splits(self.h, int(n)))
 

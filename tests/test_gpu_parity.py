@@ -668,6 +668,39 @@ def test_graph_replay_equals_eager(oa):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("shape", [(4000, 2048, 8, 2), (4000, 1700, 8, 2), (1024, 2048, 8, 2), (4096, 2047, 8, 2)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+@pytest.mark.parametrize("mode,model", [("mixed", "laplace"), ("fast", "gauss")])
+def test_covariance_and_update_in_one_launch_give_the_bits_of_two(oa, shape, mode, model):
+    """cov_update_kernel (csrc/kernels_cov_update.hip; overiva.py:158-190 for 8 channels / 2 sources where the plan's covariance
+    geometry is four frame splits: the headline shape): 4 bins x all frames per workgroup, one wave per split, the update of
+    the four bins in the same launch -- the lane chains, the order of the float64 sums over phases and splits and the update
+    chain are those of cov_dma_kernel + update_bg_kernel, so W must be THE SAME BITS, eagerly and from replayed graphs, on
+    i.i.d. and on mixture input, with ragged bin counts"""
+    T, F, M, K = shape
+    X = orc.synth_mixture(T, F, M, K, seed=8) if F % 2 else orc.synth_iid(T, F, M, seed=8)
+    outs = []
+    for fuse in (False, True):
+        for graph in (False, True):
+            with oa.Plan(T, F, M, K, model) as p:
+                p.set_precision(mode)
+                p.set_x(X)
+                p.covariance()
+                p.set_w(None)
+                active = p.set_fuse_cov_update(fuse)
+                if p.cov_splits() != 4:
+                    pytest.skip(f"the plan chose {p.cov_splits()} frame splits for this shape: the one-launch form does not apply")
+                assert active == fuse
+                p.use_graph(graph)
+                p.iterate(3)
+                p.iterate(2)
+                _, wscale = p.t_get_rinv()
+                outs.append((p.get_w(np.complex128), p.demix(True), wscale))
+    for W, Y, ws in outs[1:]:
+        assert np.array_equal(W, outs[0][0]) and np.array_equal(Y, outs[0][1]) and np.array_equal(ws, outs[0][2])
+    assert np.all(np.isfinite(outs[0][0]))
+
+
 # --------------------------------------------------------------------------------------------
 # BASELINE configs against the oracle; the headline size also through size-independent properties
 # --------------------------------------------------------------------------------------------
@@ -801,6 +834,7 @@ def test_headline_size_properties(oa):
         p.set_x(X)
         p.covariance()
         p.set_w(None)
+        p.set_fuse_cov_update(False)                   # (the one-launch form keeps the covariances in LDS: this test looks at them)
         p.iterate(3)
         rinv, wscale = p.t_get_rinv()
         What = p.t_get_what().astype(np.complex128)
