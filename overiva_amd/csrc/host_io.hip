@@ -142,7 +142,7 @@ void host_copy_rows(void* dst, size_t dst_pitch, const void* src, size_t src_pit
 
 int host_io_threads() { return pool().size(); }
 
-void host_prefault(void* ptr, size_t bytes) {
+void host_prefault(void* ptr, size_t bytes, bool may_touch) {
     if (!ptr || bytes == 0) return;
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
     CopyPool& p = pool();
@@ -169,6 +169,7 @@ void host_prefault(void* ptr, size_t bytes) {
         const uintptr_t lo_pg = lo_in & ~(uintptr_t)(page - 1);
         if (madvise((void*)lo_pg, hi - lo_pg, MADV_POPULATE_WRITE) == 0) return;
 #endif
+        if (!may_touch) return;      // (a range that holds other people's bytes: populate or nothing)
         for (uintptr_t q = lo_in; q < hi; q = (q & ~(uintptr_t)(page - 1)) + page) {
             volatile char* c = (volatile char*)q;
             *c = *c;                             // a write fault that keeps the byte
@@ -182,7 +183,7 @@ extern "C" {
 
 int oiva_host_prefault(void* ptr, long long bytes) {
     if (!ptr || bytes < 0) return oiva::fail_with(OIVA_ERR_ARG, "bad arguments");
-    oiva::host_prefault(ptr, (size_t)bytes);
+    oiva::host_prefault(ptr, (size_t)bytes, true);
     return OIVA_OK;
 }
 

@@ -1247,7 +1247,7 @@ static int demix_to_host(oiva_plan* p, void* Y_host, long long row_pitch_bytes, 
             // same mapping in ran at 8 GB/s where resident pages take 41.  Populating them costs 1-2 ms for 131 MB -- next to
             // nothing when the caller already did (overiva() does, behind its iterations) -- and runs while the first slabs
             // are computed and cross PCIe.
-            host_prefault(Y_host, pitch * (size_t)(p->T - 1) + row);
+            host_prefault(Y_host, pitch * (size_t)(p->T - 1) + row, /*may_touch*/ pitch == row);
         }
         if (e == hipSuccess) e = hipEventSynchronize(p->io_copied[k % kHostRingSlots]);
         if (e != hipSuccess) return finish(e);
