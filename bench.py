@@ -262,17 +262,18 @@ def _cov_roofline(shape, mode, cov_ms, fused=False):
                        "note": "co-limited by the vector ALU: 512 real FMAs per (bin, frame, source pair) at 16 channels against 128 at 8"}
     mc = m + m % 2
     if mode != "precise" and k >= 9 and mc >= 10 and os.environ.get("OIVA_COV_HMFMA", "1") != "0":
-        # the sources on the fp32 matrix cores (csrc/kernels_cov_hmfma.hip): per bin and 4 frames mc + 1 v_mfma_f32_16x16x4_f32
+        # the sources on the fp32 matrix cores (csrc/kernels_cov_hmfma.hip): per bin and 4 frames mc + 1 v_mfma_f32_16x16x4_f32 (16 at
+        # 16 channels, round 5: the 256 real numbers of the Hermitian half exactly)
         # (2048 flops each, all 16 source rows whatever k) and 2 + 4 (mc / 2) vector instructions forming the Hermitian products
         # (64 lanes x 2 flop slots); bound by fp32 arithmetic -- matrix and vector instructions share the 157.3 TFLOP/s ALUs
         bytes_cov = cov_algorithmic_bytes(t, f, m, k)
-        mfma = (mc + 1) * 2048.0 / 4 * t * f
+        mfma = (16 if mc == 16 else mc + 1) * 2048.0 / 4 * t * f
         valu = (2 + 4 * (mc // 2)) * 128.0 / 4 * t * f
         issued = mfma + valu
         useful = ((m * (m - 1) // 2) * (6.0 + 4.0 * k) + m * (3.0 + 2.0 * k)) * t * f     # Hermitian half, products formed once
         naive = 8.0 * k * m * m * t * f                         # naive complex count (268.4 GF at 16 x 16)
         sec = cov_ms * 1e-3
-        kname = f"cov_hmfma_kernel<{'true' if mc == 16 else 'false'}>"
+        kname = f"cov_hmfma_kernel<{'true' if mc == 16 else 'false'}, true>"
         return kname, {"bound": "fp32", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, the sources on the fp32 matrix cores, overiva.py:179)",
                        "achieved": issued / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
                        "issued_flops_per_launch": issued, "issued_matrix_flops_per_launch": mfma, "issued_vector_flops_per_launch": valu,

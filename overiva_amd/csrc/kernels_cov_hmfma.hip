@@ -25,6 +25,8 @@
 // the 128 weights of a stage (8 frames x 16 sources) ride the same ring by two 4-byte DMAs whose lane l lands exactly where
 // lane l reads its A operand.
 #include <cstdint>
+#include <cstdlib>
+#include <type_traits>
 
 #include "oiva_device.h"
 #include "cov_arith.h"
@@ -48,34 +50,35 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 // 8-byte LDS reads at per-lane addresses) and its weight -- for the first set with the counted wait for the stage's three
 // DMAs in front.  asm: hipcc drains the whole DMA queue in front of any LDS read it can see.  The reads are ISSUED by one
 // statement and WAITED for by another, so that the second set's reads fly while the first set's matrix instructions issue.
+// XOFF / WOFF: the stage and set as the instruction's immediate offset (the loop is unrolled over the ring, round 5: the
+// per-stage address additions were 4 of the 93 vector instructions beside the 34 matrix instructions of a stage).
 struct HmOps {
     float2 row;
     float2 x[8];
 };
-template <bool FIRST, bool M16>
-__device__ __forceinline__ void hm_read_issue(unsigned base, const unsigned (&ao)[9], unsigned a_w, HmOps& o, float& w) {
+template <bool FIRST, bool M16, int XOFF, int WOFF>
+__device__ __forceinline__ void hm_read_issue(const unsigned (&ax)[9], unsigned a_w, HmOps& o, float& w) {
     if constexpr (FIRST) {
-        asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w), "n"(3 * (kHmStages - 1)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b32 %0, %1 offset:%3" : "=&v"(w) : "v"(a_w), "n"(3 * (kHmStages - 1)), "n"(WOFF) : "memory");
     } else {
-        asm volatile("ds_read_b32 %0, %1" : "=&v"(w) : "v"(a_w) : "memory");
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(w) : "v"(a_w), "n"(WOFF) : "memory");
     }
     if constexpr (M16) {
-        asm volatile("ds_read_b64 %0, %1" : "=&v"(o.row) : "v"(base + ao[0]) : "memory");
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(o.row) : "v"(ax[0]), "n"(XOFF) : "memory");
         return;
     }
     asm volatile(
-        "ds_read_b64 %0, %9\n\t"
-        "ds_read_b64 %1, %10\n\t"
-        "ds_read_b64 %2, %11\n\t"
-        "ds_read_b64 %3, %12\n\t"
-        "ds_read_b64 %4, %13\n\t"
-        "ds_read_b64 %5, %14\n\t"
-        "ds_read_b64 %6, %15\n\t"
-        "ds_read_b64 %7, %16\n\t"
-        "ds_read_b64 %8, %17"
+        "ds_read_b64 %0, %9 offset:%18\n\t"
+        "ds_read_b64 %1, %10 offset:%18\n\t"
+        "ds_read_b64 %2, %11 offset:%18\n\t"
+        "ds_read_b64 %3, %12 offset:%18\n\t"
+        "ds_read_b64 %4, %13 offset:%18\n\t"
+        "ds_read_b64 %5, %14 offset:%18\n\t"
+        "ds_read_b64 %6, %15 offset:%18\n\t"
+        "ds_read_b64 %7, %16 offset:%18\n\t"
+        "ds_read_b64 %8, %17 offset:%18"
         : "=&v"(o.row), "=&v"(o.x[0]), "=&v"(o.x[1]), "=&v"(o.x[2]), "=&v"(o.x[3]), "=&v"(o.x[4]), "=&v"(o.x[5]), "=&v"(o.x[6]), "=&v"(o.x[7])
-        : "v"(base + ao[0]), "v"(base + ao[1]), "v"(base + ao[2]), "v"(base + ao[3]), "v"(base + ao[4]), "v"(base + ao[5]), "v"(base + ao[6]),
-          "v"(base + ao[7]), "v"(base + ao[8])
+        : "v"(ax[0]), "v"(ax[1]), "v"(ax[2]), "v"(ax[3]), "v"(ax[4]), "v"(ax[5]), "v"(ax[6]), "v"(ax[7]), "v"(ax[8]), "n"(XOFF)
         : "memory");
 }
 // (the wait names no register -- tied operands of struct members are not supported -- so a scheduling barrier behind it keeps
@@ -85,13 +88,24 @@ __device__ __forceinline__ void hm_read_wait() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+template <int I>
+using hm_ic = std::integral_constant<int, I>;
+
 // M16: exactly 16 channels -- channel (n + c) mod 16 of the lane's frame sits c lanes further in its 16-lane row, so the
 // partner of every product is a DPP row rotation of the lane's own operand (a modifier of the multiply / FMA itself): one
 // 8-byte LDS read per lane, set and stage instead of nine (which, four frames hitting the same banks, kept the LDS pipe of
 // the CU busier than the matrix pipes).  Fewer channels: the partners are gathered from LDS.
-template <bool M16>
+//   With 16 channels the distance c = 8 pairs every channel with its opposite twice: its real and imaginary parts share ONE
+//   group (lanes 0..7 the real part of (n, n + 8), lanes 8..15 the imaginary part of (n - 8, n), by the bank mask of the DPP
+//   instructions) -- 16 matrix instructions per 4 frames, the 256 real numbers of the Hermitian half exactly, instead of 17.
+// BUF: the DMAs in buffer form -- the resource descriptor (base, bytes left) steps through the frames on the SCALAR unit, the
+// lane's offset is a constant, frames past the end read as zero by the descriptor's range check: no vector instruction for
+// addresses (the flat form spent 21 per stage on them, three at a quarter of the rate; on this chip vector and matrix
+// instructions share the ALUs and their times add).  Needs a split's frames + 35 within 4 GB of X; else the flat form.
+template <bool M16, bool BUF>
 __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __restrict__ X, const float* __restrict__ Wt,
                                                               double* __restrict__ Vpart, int T, int F, int M, int Mv, int K, int tc) {
+    constexpr int NG = M16 ? 16 : 17;
     constexpr int kRingBytes = kWaves * kHmStages * kHmStage;
     constexpr int kScratchBytes = (int)sizeof(float) * kHmChunk * kHmLdsStride;
     __shared__ float4 ring[(kRingBytes > kScratchBytes ? kRingBytes : kScratchBytes) / 16 + 1];
@@ -106,13 +120,13 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     const int t_end = min(T, t_begin + tc);
     const int nstages = (t_end - t_begin + 8 * kHmFrames - 1) / (8 * kHmFrames);
 
-    // [accumulator set][group]: group 0 = |x_n|^2, 2 c - 1 / 2 c = real / imaginary part of x_n conj(x_(n + c) mod M), c = 1 .. 8;
-    // lane (q, n) holds sources 4 q + r of its entry
-    f32x4 acc[2][17];
+    // [accumulator set][group]: group 0 = |x_n|^2, 2 c - 1 / 2 c = real / imaginary part of x_n conj(x_(n + c) mod M), c = 1 .. 8
+    // (M16: c = 1 .. 7, group 15 = both parts of c = 8); lane (q, n) holds sources 4 q + r of its entry
+    f32x4 acc[2][NG];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < 17; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NG; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int MH = M / 2;
 
     // ---- DMA side: lane l moves 16-byte piece l & 7 of frame slot l >> 4, half (l & 15) >> 3: the half-0 frame of slot q is
@@ -124,32 +138,81 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     const char* xbytes = reinterpret_cast<const char*>(X);
     const size_t row_bytes = (size_t)F * M * 8;
     const char* run0 = xbytes + (size_t)f0 * M * 8 + piece_off;
-    auto issue = [&](int i, int s) {
-        const int t0 = t_begin + wave + 4 * (2 * kHmFrames * i + q), t1 = t0 + 4 * kHmFrames;
-        const int tx = half ? t1 : t0;
-        const int tcl = min(i < nstages ? tx : T - 1, T - 1);
-        __builtin_amdgcn_global_load_lds((gvoid_t*)(run0 + (size_t)tcl * row_bytes), (lvoid_t*)(wring + s * kHmStage), 16, 0, 0);
-        const int tw0 = (i < nstages && t0 < t_end) ? t0 : T, tw1 = (i < nstages && t1 < t_end) ? t1 : T;
-        __builtin_amdgcn_global_load_lds((gvoid_t*)(Wt + (size_t)tw0 * kHmWeightStride + n), (lvoid_t*)(wring + s * kHmStage + kHmX), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((gvoid_t*)(Wt + (size_t)tw1 * kHmWeightStride + n), (lvoid_t*)(wring + s * kHmStage + kHmX + 256), 4, 0, 0);
+    // (buffer form) the workgroup's bin at the first frame of its split is offset 0 of stage 0's descriptor; a stage is 32 frames
+    const unsigned row32 = (unsigned)row_bytes;            // (the launch checks 36 rows < 4 GB)
+    const unsigned col_off = (unsigned)f0 * (unsigned)M * 8u;
+    const unsigned xvoff = (unsigned)(wave + 4 * q + 16 * half) * row32 + piece_off;
+    const unsigned wvoff0 = (unsigned)((wave + 4 * q) * kHmWeightStride + n) * 4u;
+    const unsigned wvoff1 = wvoff0 + 4u * kHmFrames * kHmWeightStride * 4u;
+    auto issue = [&](int i, auto sc) {
+        constexpr int s = decltype(sc)::value;
+        char* dst = wring + s * kHmStage;
+        if constexpr (BUF) {
+            // (all of this on the scalar unit: 32-bit compares only -- there is no scalar 64-bit compare)
+            const int tx = t_begin + 8 * kHmFrames * i, fl = T - tx;                                  // frames left
+            // bytes of X from the descriptor's base on, as far as this stage's 32 frames reach (min / max only: a select would
+            // leave the scalar unit and the descriptor would be rebuilt per lane)
+            //   rec = max(min(max(fl, 0), 32) * row32, col_off) - col_off
+            // (asm: hipcc picks v_med3_i32 and a clamped vector subtraction for this, and a descriptor word that lives in a vector
+            //  register is applied lane by lane in a loop)
+            unsigned rec;
+            asm("s_max_i32 %0, %1, 0\n\t"
+                "s_min_i32 %0, %0, %4\n\t"
+                "s_mul_i32 %0, %0, %2\n\t"
+                "s_max_u32 %0, %0, %3\n\t"
+                "s_sub_u32 %0, %0, %3"
+                : "=&s"(rec)
+                : "s"(fl), "s"(row32), "s"(col_off), "n"(8 * kHmFrames)
+                : "scc");
+            const char* xb = xbytes + ((size_t)(unsigned)min(tx, T) * row32 + col_off);
+            const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), 0, (int)rec, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lvoid_t*)dst, 16, (int)xvoff, 0, 0, 0);
+            const int tw = min(t_begin + 8 * kHmFrames * i, T);
+            const auto wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt + (size_t)tw * kHmWeightStride), 0, (T - tw) * kHmWeightStride * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lvoid_t*)(dst + kHmX), 4, (int)wvoff0, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lvoid_t*)(dst + kHmX + 256), 4, (int)wvoff1, 0, 0, 0);
+        } else {
+            const int t0 = t_begin + wave + 4 * (2 * kHmFrames * i + q), t1 = t0 + 4 * kHmFrames;
+            const int tx = half ? t1 : t0;
+            const int tcl = min(i < nstages ? tx : T - 1, T - 1);
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(run0 + (size_t)tcl * row_bytes), (lvoid_t*)dst, 16, 0, 0);
+            const int tw0 = (i < nstages && t0 < t_end) ? t0 : T, tw1 = (i < nstages && t1 < t_end) ? t1 : T;
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(Wt + (size_t)tw0 * kHmWeightStride + n), (lvoid_t*)(dst + kHmX), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(Wt + (size_t)tw1 * kHmWeightStride + n), (lvoid_t*)(dst + kHmX + 256), 4, 0, 0);
+        }
     };
 
-    // ---- operand addresses of this lane inside a frame slot of set 0 (set 1 at + 128 bytes): its own channel, then the
-    //      channels (n + c) mod M; lanes n >= M (fewer than 16 channels) read channel 0 and produce entries that are dropped
+    // ---- operand addresses of this lane inside a frame slot of set 0 of stage 0 (set 1 at + 128 bytes, stage s at + s stages):
+    //      its own channel, then the channels (n + c) mod M; lanes n >= M (fewer than 16 channels) read channel 0 and produce
+    //      entries that are dropped
     const unsigned lbase = (unsigned)(uintptr_t)wring + (unsigned)(q * kHmSlot);
     const int nn = n < M ? n : 0;
-    unsigned ao[9];
-    ao[0] = 8u * (unsigned)nn;
+    unsigned ax[9];
+    ax[0] = lbase + 8u * (unsigned)nn;
 #pragma unroll
-    for (int c = 1; c <= 8; ++c) ao[c] = 8u * (unsigned)((nn + c) % M);
-    const unsigned a_w0 = (unsigned)(uintptr_t)wring + (unsigned)kHmX + 4u * (unsigned)lane;
-    const unsigned a_w1 = a_w0 + 256u;
-    constexpr unsigned setoff = 128u;
+    for (int c = 1; c <= 8; ++c) ax[c] = lbase + 8u * (unsigned)((nn + c) % M);
+    const unsigned a_w = (unsigned)(uintptr_t)wring + 4u * (unsigned)lane;
+    constexpr int setoff = 128;
 
-    // the M + 1 groups of one accumulator set: a product (multiply, FMA onto it) and one MFMA with the stage's weights each
-    auto groups = [&](const HmOps& o, float w, f32x4 (&a)[17]) {
+    // the groups of one accumulator set: a product (multiply, FMA onto it) and one MFMA with the stage's weights each
+    auto groups = [&](const HmOps& o, float w, f32x4 (&a)[NG]) {
+        float both8;
+        if constexpr (M16) {
+            // c = 8: lanes 0..7 of a row  Re x_n conj x_(n + 8) = fma(xi_n, xi_m, xr_n xr_m),
+            //        lanes 8..15 (own channel m = n' + 8, partner n')  Im x_n' conj x_m = fma(xi_n', xr_m, -(xr_n' xi_m))
+            // -- the same operations in the same order as the two groups this one replaces.  (s_nop: the matrix instruction
+            // that follows reads the register the last instruction of the block writes, see below.)
+            asm("v_mul_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                "v_mul_f32_dpp %0, -%1, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                "v_fmac_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                "v_fmac_f32_dpp %0, %2, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                "s_nop 1"
+                : "=&v"(both8)
+                : "v"(o.row.x), "v"(o.row.y));
+        }
         a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, fmaf(o.row.y, o.row.y, o.row.x * o.row.x), a[0], 0, 0, 0);
-        static_for<8>([&](auto cc) {
+        if constexpr (M16) a[15] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, both8, a[15], 0, 0, 0);
+        static_for<M16 ? 7 : 8>([&](auto cc) {
             constexpr int c = decltype(cc)::value + 1;
             if constexpr (M16) {
                 // the partner channel m = (n + c) mod 16 is the lane's own operand rotated by c lanes inside its 16-lane row
@@ -179,30 +242,55 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
         });
     };
     // one stage: both sets; the second set's operands are read while the first set's matrix instructions issue
-    auto stage = [&](int s) {
-        const unsigned so = (unsigned)(s * kHmStage);
+    auto stage = [&](auto sc) {
+        constexpr int so = decltype(sc)::value * kHmStage;
         float w0, w1;
         HmOps o0, o1;
-        hm_read_issue<true, M16>(lbase + so, ao, a_w0 + so, o0, w0);
+        hm_read_issue<true, M16, so, so + kHmX>(ax, a_w, o0, w0);
         hm_read_wait();
-        hm_read_issue<false, M16>(lbase + so + setoff, ao, a_w1 + so, o1, w1);
+        hm_read_issue<false, M16, so + setoff, so + kHmX + 256>(ax, a_w, o1, w1);
         groups(o0, w0, acc[0]);
         hm_read_wait();
         groups(o1, w1, acc[1]);
     };
 
-    issue(0, 0);
-    issue(1, 1);
-    issue(2, 2);
-    for (int i = 0; i < nstages; ++i) {
-        issue(i + 3, (i + 3) & 3);
-        stage(i & 3);
+    // the ring of four stages unrolled: stage i sits in slot i mod 4, its successor i + 3 is requested before it is consumed
+    // (every stage of the loop requests exactly three DMAs -- the counted wait of the first read depends on it; requests past
+    //  the split's last stage land in slots nobody reads)
+    issue(0, hm_ic<0>{});
+    issue(1, hm_ic<1>{});
+    issue(2, hm_ic<2>{});
+    int i = 0;
+    for (; i + 4 <= nstages; i += 4) {
+        issue(i + 3, hm_ic<3>{});
+        stage(hm_ic<0>{});
+        issue(i + 4, hm_ic<0>{});
+        stage(hm_ic<1>{});
+        issue(i + 5, hm_ic<1>{});
+        stage(hm_ic<2>{});
+        issue(i + 6, hm_ic<2>{});
+        stage(hm_ic<3>{});
+    }
+    if (i < nstages) {
+        issue(i + 3, hm_ic<3>{});
+        stage(hm_ic<0>{});
+        ++i;
+    }
+    if (i < nstages) {
+        issue(i + 3, hm_ic<0>{});
+        stage(hm_ic<1>{});
+        ++i;
+    }
+    if (i < nstages) {
+        issue(i + 3, hm_ic<1>{});
+        stage(hm_ic<2>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the DMA queue before the ring becomes reduction scratch
 
     // ---- the eight chains (4 waves x 2 sets) added in float64, fixed order; accumulator r of group grp of lane (q, n) is
     //      source 4 q + r, entry: grp 0 the diagonal n; grp 2 c - 1 / 2 c the real / imaginary part of the pair
-    //      (n, (n + c) mod M), stored under its ordered form (i < j): the imaginary part changes sign when the pair wraps.
+    //      (n, (n + c) mod M), stored under its ordered form (i < j): the imaginary part changes sign when the pair wraps
+    //      (M16, grp 15: lanes 0..7 the real part of (n, n + 8), lanes 8..15 the imaginary part of (n - 8, n)).
     //      A round = 4 groups; wave w adds the eight values of accumulator r = w of each, so that group, pair distance and
     //      re / im are compile-time and only (source row, channel) come from the lane.
     float* lds = reinterpret_cast<float*>(ring);
@@ -210,7 +298,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     double* vout = Vpart + (((size_t)blockIdx.y * F + f0) * K + 4 * q + wave) * NA;
     const bool live = 4 * q + wave < K && n < M;
 #pragma unroll
-    for (int g0 = 0; g0 < 17; g0 += 4) {
+    for (int g0 = 0; g0 < NG; g0 += 4) {
         __syncthreads();
 #pragma unroll
         for (int v = 0; v < 4; ++v)
@@ -218,12 +306,12 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    if (g0 + v < 17) lds[((v * 4 + r) * 2 + h) * kHmLdsStride + tid] = acc[h][g0 + v][r];
+                    if (g0 + v < NG) lds[((v * 4 + r) * 2 + h) * kHmLdsStride + tid] = acc[h][g0 + v][r];
         __syncthreads();
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int grp = g0 + v;                 // compile-time
-            if (grp >= 17) continue;
+            if (grp >= NG) continue;
             const int c = (grp + 1) >> 1, im = (grp + 1) & 1;            // grp 2c-1: re, 2c: im   (grp 0: the diagonal)
             double s = 0.;
 #pragma unroll
@@ -235,6 +323,10 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
             if (grp == 0) {
                 if (n >= Mv) continue;
                 pos = n;
+            } else if (M16 && grp == 15) {
+                const int i8 = n & 7, j8 = i8 + 8;
+                if (j8 >= Mv) continue;
+                pos = herm_pair_index(Mv, i8, j8) + (n >> 3);
             } else {
                 if (c > MH || (c == MH && n >= MH)) continue;             // (c = M/2: the upper half of the lanes repeats the lower)
                 const int mm = n + c >= M ? n + c - M : n + c;
@@ -400,8 +492,15 @@ hipError_t launch_cov_hmfma64(hipStream_t s, const float2* X, const double* Wt, 
 hipError_t launch_cov_hmfma(hipStream_t s, const float2* X, const float* Wt, double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g) {
     if (!cov_hmfma_supported(M, K) || Mv > M || Mv < M - 1 || Wt == nullptr || g.tc % (8 * kHmFrames) != 0) return hipErrorInvalidValue;
     const dim3 grid(F, g.nsplit, 1), block(kBlock);
-    if (M == 16) return launch_dominant(cov_hmfma_kernel<true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
-    return launch_dominant(cov_hmfma_kernel<false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+    // the buffer form of the DMAs: a lane's offset from the first frame of a stage is 32 bits
+    static const bool flat_forced = [] { const char* v = std::getenv("OIVA_HMFMA_FLAT"); return v && v[0] == '1'; }();
+    const bool buf = !flat_forced && (size_t)36 * F * M * 8 < 0xffffffffull;
+    if (M == 16) {
+        if (buf) return launch_dominant(cov_hmfma_kernel<true, true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+        return launch_dominant(cov_hmfma_kernel<true, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+    }
+    if (buf) return launch_dominant(cov_hmfma_kernel<false, true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+    return launch_dominant(cov_hmfma_kernel<false, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
 }
 
 }  // namespace oiva
