@@ -352,6 +352,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
 constexpr int kHm64Stage = kHmX + 1024;                 // + 2 halves x (low, high) x 64 words
 constexpr int kHm64Chunk = 16;                          // doubles per LDS round of the epilogue: 4 groups x 4
 
+template <bool BUF>
 __global__ __launch_bounds__(kBlock, 2) void cov_hmfma64_kernel(const float2* __restrict__ X, const double* __restrict__ Wt,
                                                                 double* __restrict__ Vpart, int T, int F, int Mv, int K, int tc) {
     constexpr int M = 16, MH = 8;
@@ -375,25 +376,57 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma64_kernel(const float2* __
 
     char* wring = reinterpret_cast<char*>(ring) + wave * (kHmStages * kHm64Stage);       // wave-uniform
     const int half = (lane >> 3) & 1;
-    const char* run0 = reinterpret_cast<const char*>(X) + (size_t)f0 * M * 8 + (unsigned)(lane & 7) * 16u;
+    const char* xbytes = reinterpret_cast<const char*>(X);
+    const char* run0 = xbytes + (size_t)f0 * M * 8 + (unsigned)(lane & 7) * 16u;
     const size_t row_bytes = (size_t)F * M * 8;
     const float* wt32 = reinterpret_cast<const float*>(Wt);
-    auto issue = [&](int i, int s) {
-        const int t0 = t_begin + wave + 4 * (2 * kHmFrames * i + q), t1 = t0 + 4 * kHmFrames;
-        const int tx = half ? t1 : t0;
-        const int tcl = min(i < nstages ? tx : T - 1, T - 1);
+    // (buffer form, as in the float32 kernel: descriptors stepped on the scalar unit, constant lane offsets, range-checked tails)
+    const unsigned row32 = (unsigned)row_bytes;
+    const unsigned col_off = (unsigned)f0 * (unsigned)M * 8u;
+    const unsigned xvoff = (unsigned)(wave + 4 * q + 16 * half) * row32 + (unsigned)(lane & 7) * 16u;
+    const unsigned wv0 = (unsigned)((wave + 4 * q) * kHmWeightStride + n) * 8u, wv1 = wv0 + 4u;
+    const unsigned wv2 = wv0 + 4u * kHmFrames * kHmWeightStride * 8u, wv3 = wv2 + 4u;
+    auto issue = [&](int i, auto sc) {
+        constexpr int s = decltype(sc)::value;
         char* dst = wring + s * kHm64Stage;
-        __builtin_amdgcn_global_load_lds((gvoid_t*)(run0 + (size_t)tcl * row_bytes), (lvoid_t*)dst, 16, 0, 0);
-        const int tw0 = (i < nstages && t0 < t_end) ? t0 : T, tw1 = (i < nstages && t1 < t_end) ? t1 : T;
-        const float* w0 = wt32 + ((size_t)tw0 * kHmWeightStride + n) * 2;
-        const float* w1 = wt32 + ((size_t)tw1 * kHmWeightStride + n) * 2;
-        __builtin_amdgcn_global_load_lds((gvoid_t*)w0, (lvoid_t*)(dst + kHmX), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((gvoid_t*)(w0 + 1), (lvoid_t*)(dst + kHmX + 256), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((gvoid_t*)w1, (lvoid_t*)(dst + kHmX + 512), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((gvoid_t*)(w1 + 1), (lvoid_t*)(dst + kHmX + 768), 4, 0, 0);
+        if constexpr (BUF) {
+            const int tx = t_begin + 8 * kHmFrames * i, fl = T - tx;
+            unsigned rec;
+            asm("s_max_i32 %0, %1, 0\n\t"
+                "s_min_i32 %0, %0, %4\n\t"
+                "s_mul_i32 %0, %0, %2\n\t"
+                "s_max_u32 %0, %0, %3\n\t"
+                "s_sub_u32 %0, %0, %3"
+                : "=&s"(rec)
+                : "s"(fl), "s"(row32), "s"(col_off), "n"(8 * kHmFrames)
+                : "scc");
+            const int tw = min(tx, T);
+            const char* xb = xbytes + ((size_t)(unsigned)tw * row32 + col_off);
+            const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), 0, (int)rec, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lvoid_t*)dst, 16, (int)xvoff, 0, 0, 0);
+            const auto wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Wt + (size_t)tw * kHmWeightStride), 0, (T - tw) * kHmWeightStride * 8, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lvoid_t*)(dst + kHmX), 4, (int)wv0, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lvoid_t*)(dst + kHmX + 256), 4, (int)wv1, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lvoid_t*)(dst + kHmX + 512), 4, (int)wv2, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lvoid_t*)(dst + kHmX + 768), 4, (int)wv3, 0, 0, 0);
+        } else {
+            const int t0 = t_begin + wave + 4 * (2 * kHmFrames * i + q), t1 = t0 + 4 * kHmFrames;
+            const int tx = half ? t1 : t0;
+            const int tcl = min(i < nstages ? tx : T - 1, T - 1);
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(run0 + (size_t)tcl * row_bytes), (lvoid_t*)dst, 16, 0, 0);
+            const int tw0 = (i < nstages && t0 < t_end) ? t0 : T, tw1 = (i < nstages && t1 < t_end) ? t1 : T;
+            const float* w0 = wt32 + ((size_t)tw0 * kHmWeightStride + n) * 2;
+            const float* w1 = wt32 + ((size_t)tw1 * kHmWeightStride + n) * 2;
+            __builtin_amdgcn_global_load_lds((gvoid_t*)w0, (lvoid_t*)(dst + kHmX), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(w0 + 1), (lvoid_t*)(dst + kHmX + 256), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvoid_t*)w1, (lvoid_t*)(dst + kHmX + 512), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(w1 + 1), (lvoid_t*)(dst + kHmX + 768), 4, 0, 0);
+        }
     };
     const unsigned a_x = (unsigned)(uintptr_t)wring + (unsigned)(q * kHmSlot + 8 * n);
-    const unsigned a_w = (unsigned)(uintptr_t)wring + (unsigned)kHmX + 4u * (unsigned)lane;
+    unsigned a_ws[kHmStages];
+#pragma unroll
+    for (int s = 0; s < kHmStages; ++s) a_ws[s] = (unsigned)(uintptr_t)wring + (unsigned)(s * kHm64Stage + kHmX) + 4u * (unsigned)lane;
 
     auto groups = [&](v2f row, double w) {
         const double xr = (double)row.x, xi = (double)row.y;
@@ -406,29 +439,51 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma64_kernel(const float2* __
             acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(w, fma(xi, pr, -(xr * pi)), acc[2 * c], 0, 0, 0);           // Im x_n conj x_m
         });
     };
-    auto stage = [&](int s) {
-        const unsigned so = (unsigned)(s * kHm64Stage);
+    auto stage = [&](auto sc) {
+        constexpr int so = decltype(sc)::value * kHm64Stage;
         v2f r0, r1;
         double w0, w1;
+        // (the 8-bit offsets of ds_read2_b32 do not reach across stages: one address register per stage for the weights)
         asm volatile("s_waitcnt vmcnt(%4)\n\t"
-                     "ds_read_b64 %0, %5\n\t"
+                     "ds_read_b64 %0, %5 offset:%7\n\t"
                      "ds_read2_b32 %2, %6 offset1:64\n\t"
-                     "ds_read_b64 %1, %5 offset:128\n\t"
+                     "ds_read_b64 %1, %5 offset:%8\n\t"
                      "ds_read2_b32 %3, %6 offset0:128 offset1:192\n\t"
                      "s_waitcnt lgkmcnt(0)"
                      : "=&v"(r0), "=&v"(r1), "=&v"(w0), "=&v"(w1)
-                     : "n"(5 * (kHmStages - 1)), "v"(a_x + so), "v"(a_w + so)
+                     : "n"(5 * (kHmStages - 1)), "v"(a_x), "v"(a_ws[decltype(sc)::value]), "n"(so), "n"(so + 128)
                      : "memory");
         groups(r0, w0);
         groups(r1, w1);
     };
 
-    issue(0, 0);
-    issue(1, 1);
-    issue(2, 2);
-    for (int i = 0; i < nstages; ++i) {
-        issue(i + 3, (i + 3) & 3);
-        stage(i & 3);
+    issue(0, hm_ic<0>{});
+    issue(1, hm_ic<1>{});
+    issue(2, hm_ic<2>{});
+    int i = 0;
+    for (; i + 4 <= nstages; i += 4) {
+        issue(i + 3, hm_ic<3>{});
+        stage(hm_ic<0>{});
+        issue(i + 4, hm_ic<0>{});
+        stage(hm_ic<1>{});
+        issue(i + 5, hm_ic<1>{});
+        stage(hm_ic<2>{});
+        issue(i + 6, hm_ic<2>{});
+        stage(hm_ic<3>{});
+    }
+    if (i < nstages) {
+        issue(i + 3, hm_ic<3>{});
+        stage(hm_ic<0>{});
+        ++i;
+    }
+    if (i < nstages) {
+        issue(i + 3, hm_ic<0>{});
+        stage(hm_ic<1>{});
+        ++i;
+    }
+    if (i < nstages) {
+        issue(i + 3, hm_ic<1>{});
+        stage(hm_ic<2>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the DMA queue before the ring becomes reduction scratch
 
@@ -486,15 +541,19 @@ bool cov_hmfma64_supported(int M, int K) { return M == 16 && K >= 9 && K <= 16; 
 
 hipError_t launch_cov_hmfma64(hipStream_t s, const float2* X, const double* Wt, double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g) {
     if (!cov_hmfma64_supported(M, K) || Mv > M || Mv < M - 1 || Wt == nullptr || g.tc % (8 * kHmFrames) != 0) return hipErrorInvalidValue;
-    return launch_dominant(cov_hmfma64_kernel, dim3(F, g.nsplit, 1), dim3(kBlock), 0, s, X, Wt, Vpart, T, F, Mv, K, g.tc);
+    const char* flat = std::getenv("OIVA_HMFMA_FLAT");
+    if (!(flat && flat[0] == '1') && (size_t)36 * F * M * 8 < 0xffffffffull)
+        return launch_dominant(cov_hmfma64_kernel<true>, dim3(F, g.nsplit, 1), dim3(kBlock), 0, s, X, Wt, Vpart, T, F, Mv, K, g.tc);
+    return launch_dominant(cov_hmfma64_kernel<false>, dim3(F, g.nsplit, 1), dim3(kBlock), 0, s, X, Wt, Vpart, T, F, Mv, K, g.tc);
 }
 
 hipError_t launch_cov_hmfma(hipStream_t s, const float2* X, const float* Wt, double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g) {
     if (!cov_hmfma_supported(M, K) || Mv > M || Mv < M - 1 || Wt == nullptr || g.tc % (8 * kHmFrames) != 0) return hipErrorInvalidValue;
     const dim3 grid(F, g.nsplit, 1), block(kBlock);
     // the buffer form of the DMAs: a lane's offset from the first frame of a stage is 32 bits
-    static const bool flat_forced = [] { const char* v = std::getenv("OIVA_HMFMA_FLAT"); return v && v[0] == '1'; }();
-    const bool buf = !flat_forced && (size_t)36 * F * M * 8 < 0xffffffffull;
+    // ($OIVA_HMFMA_FLAT=1, read at every launch: the flat form whatever the size -- tests compare the two bit for bit)
+    const char* flat = std::getenv("OIVA_HMFMA_FLAT");
+    const bool buf = !(flat && flat[0] == '1') && (size_t)36 * F * M * 8 < 0xffffffffull;
     if (M == 16) {
         if (buf) return launch_dominant(cov_hmfma_kernel<true, true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
         return launch_dominant(cov_hmfma_kernel<true, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);

@@ -240,6 +240,35 @@ def test_sources_on_the_matrix_cores_against_the_vector_alu_kernel(oa, shape):
     assert orc.rel_err(V[True], ref) < 3e-6 and orc.rel_err(V[False], ref) < 3e-6
 
 
+@pytest.mark.parametrize("shape", [(33, 3, 16, 16), (97, 2, 16, 13), (160, 3, 16, 16), (223, 2, 15, 15), (129, 3, 12, 12), (96, 2, 14, 9), (2100, 2, 16, 16)])
+def test_matrix_core_kernel_ring_tails_and_both_forms_of_its_loads(oa, shape, monkeypatch):
+    """cov_hmfma_kernel, round 5: the ring of four stages is unrolled (a split of 1, 2, 3 stages and of 4 n + 1 .. 3 runs the
+    tail code), the loads are buffer-form DMAs whose descriptor steps through the frames on the scalar unit and whose range check
+    zeroes the frames past T (the flat form clamps addresses instead; $OIVA_HMFMA_FLAT=1), and at 16 channels the two parts of the
+    pair distance 8 share one group of the matrix instruction.  The two forms of the loads give the SAME BITS; both sit within the
+    single-pass bound of the oracle; one split and several."""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F, M, seed=37)
+    rinv = np.random.default_rng(7).gamma(2.0, 1.0, (T, K)).astype(np.float32)
+    ref = orc.weighted_cov_all(X, rinv.astype(np.float64))
+    for splits in (1, 0):
+        V = {}
+        for flat in ("0", "1"):
+            monkeypatch.setenv("OIVA_HMFMA_FLAT", flat)
+            with oa.Plan(T, F, M, K, "laplace") as p:
+                p.set_precision("mixed")
+                if splits:
+                    p.set_cov_splits(splits)
+                p.set_x(X)
+                p.covariance()
+                p.t_set_rinv(rinv)
+                p.t_run_weighted_cov()
+                V[flat] = p.t_get_v(np.complex128)
+        assert np.array_equal(V["0"], V["1"])
+        assert orc.rel_err(V["0"], ref) < (2e-5 if splits == 1 and T > 2000 else 3e-6)
+        assert np.array_equal(V["0"], np.conj(np.swapaxes(V["0"], -1, -2)))
+
+
 @pytest.mark.parametrize("shape", [(400, 6, 16, 16), (333, 5, 16, 9), (180, 3, 15, 15), (70, 2, 16, 12)])
 def test_sources_on_the_fp64_matrix_cores_against_the_vector_alu_kernel(oa, shape):
     """`precise`, 16 channels (15: padded copy of X), 9..16 sources: the same GEMM per bin on the fp64 matrix cores
