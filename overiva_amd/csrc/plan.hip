@@ -337,7 +337,13 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         nsplit = std::min(nsplit, cap);
         // four frame phases per workgroup instead of 16: float32 chains four times as long at equal splits; with the
         // float64 per-bin algebra behind it the pass takes at least 8 splits (see the 10..16-channel kernel above)
-        if (g.pair32 && p->upd_f64()) nsplit = std::max(nsplit, mixed_min_splits(p->n_cu * bpc, g.nbg * nz, p->T));
+        // (round 5: on a short frame axis the bound is the chain itself -- T / (4 nsplit) <= 64 frames, what 4 splits give just below
+        //  1024 frames -- not 4 splits whatever T: at the reference's 2049 bins x 235 frames the forced fourth split cost 8 / 4
+        //  sources 26.8 against 21.2 us on the pass (iteration 74.4 -> 69.2 us), 8 / 3 23.0 against 19.2 (63.5 -> 59.4))
+        if (g.pair32 && p->upd_f64()) {
+            const int by_chain = p->T >= 1024 ? 8 : std::min(4, ceil_div(p->T, 256));
+            nsplit = std::max(nsplit, std::min(by_chain, mixed_min_splits(p->n_cu * bpc, g.nbg * nz, p->T)));
+        }
     }
     g.tc = round_up(ceil_div(p->T, nsplit), quantum);
     g.nsplit = ceil_div(p->T, g.tc);
