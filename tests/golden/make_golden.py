@@ -112,6 +112,10 @@ BIG_CASES = [
     ("eb", 1024, 4, 16, 16),
     ("ta", 256, 5, 15, 15),
     ("tb", 1024, 3, 15, 15),
+    # (round 5) 8 channels with 3 and 4 sources + background at the reference's own frame count: the four-sources-per-pass
+    # covariance kernel (cov_pair32_kernel) and the Gram form of the update had no fixture from the real reference
+    ("v", 235, 33, 8, 4),
+    ("z", 160, 40, 8, 3),
 ]
 BIG_ITERS = (1, 5, 20)
 
