@@ -181,3 +181,34 @@ def test_no_kernel_of_the_iteration_uses_scratch_memory():
     allowed = ("ogive_init_kernel", "ogive_switch_kernel")
     bad = {n: u["scratch"] for n, u in usage.items() if u.get("scratch", 0) > 0 and not any(a in n for a in allowed)}
     assert not bad, bad
+
+
+def test_host_prefault_is_host_only_and_keeps_the_contents(lib):
+    """oiva_host_prefault (csrc/host_io.hip: the copy-thread pool populating the pages of a destination) touches no device: it
+    runs here.  Contents kept on an unaligned range, on a range shorter than a page, from four caller threads at once (the pool
+    takes one call at a time); bad arguments are refused."""
+    import ctypes as C
+    import threading
+
+    a = np.arange(2_000_001, dtype=np.float64)[1:]         # not page aligned
+    keep = a.copy()
+    assert lib.oiva_host_prefault(C.c_void_p(a.ctypes.data), a.nbytes) == 0
+    assert np.array_equal(a, keep)
+    small = np.arange(7, dtype=np.uint8)
+    assert lib.oiva_host_prefault(C.c_void_p(small.ctypes.data), small.nbytes) == 0 and small.tolist() == list(range(7))
+    assert lib.oiva_host_prefault(C.c_void_p(small.ctypes.data), 0) == 0
+    assert lib.oiva_host_prefault(None, 16) != 0 and lib.oiva_host_prefault(C.c_void_p(small.ctypes.data), -1) != 0
+    bufs = [np.full(1 << 20, i, np.int32) for i in range(4)]
+    errs = []
+
+    def work(b):
+        for _ in range(20):
+            if lib.oiva_host_prefault(C.c_void_p(b.ctypes.data), b.nbytes) != 0:
+                errs.append(1)
+
+    th = [threading.Thread(target=work, args=(b,)) for b in bufs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs and all(np.all(b == i) for i, b in enumerate(bufs))
