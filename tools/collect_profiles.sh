@@ -74,6 +74,11 @@ python3 $ROOT/tools/cfg5_cov_sweep.py > "$OUT/cfg5_cov_sweep.log" 2>&1
 python3 $ROOT/tools/e2e_phases.py > "$OUT/e2e_phases.log" 2>&1
 python3 $ROOT/tools/e2e_host.py > "$OUT/e2e_host.log" 2>&1
 python3 $ROOT/tools/stage_times_reference_shapes.py > "$OUT/stage_times_reference_shapes.log" 2>&1
+# (round 5) the 2- / 4-GPU shards without and with the in-kernel exchange, alternating; the sweep shapes against forced frame splits;
+# the achieved parity errors of every end-to-end row
+python3 $ROOT/tools/shard_fused_ab.py > "$OUT/shard_fused_ab.log" 2>&1
+python3 $ROOT/tools/sweep_shape_splits.py > "$OUT/sweep_shape_splits.log" 2>&1
+(cd $ROOT && rm -f "$OUT/parity.jsonl" && OIVA_PARITY_LOG="$OUT/parity.jsonl" python3 -m pytest tests/test_gpu_parity.py -m gpu -q > "$OUT/parity_pytest.log" 2>&1)
 # keep what travels back small: drop the raw kernel traces of the --stats runs
 find "$OUT" -name "*_kernel_trace.csv" -path "*stats_*" -delete
 find "$OUT" -name "*_agent_info.csv" -delete

@@ -134,6 +134,20 @@ def main():
             print(f"{k}: matrix pipes busy {cs['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (cs['GRBM_GUI_ACTIVE'] / 8):.2f}")
     for k, t in traffic.items():
         print(f"{k}: HBM bytes per launch {t['hbm_bytes_per_launch'] / 1e6:.1f} MB")
+    # the tools' own logs, as they are (minus the loader's complaint about a file the image lacks)
+    for name in ("shard_step.log", "launch_cost.log", "resident_trace_shard8.log", "resident_trace_shard8_loopback8.log",
+                 "resident_configs.log", "cfg5_cov_sweep.log", "e2e_phases.log", "e2e_host.log", "stage_times_reference_shapes.log",
+                 "shard_fused_ab.log", "sweep_shape_splits.log"):
+        path = os.path.join(SRC, name)
+        if os.path.exists(path):
+            lines = [l for l in open(path).read().splitlines() if "amdgpu.ids" not in l]
+            open(os.path.join(DST, f"{TAG}_{name}"), "w").write("\n".join(lines) + "\n")
+    # the achieved parity errors of every end-to-end row (tests/test_gpu_parity.py with $OIVA_PARITY_LOG)
+    pj = os.path.join(SRC, "parity.jsonl")
+    if os.path.exists(pj):
+        import subprocess
+        md = subprocess.run([sys.executable, os.path.join(REPO, "tools", "parity_table.py"), pj], capture_output=True, text=True, check=True).stdout
+        open(os.path.join(DST, f"{TAG}_parity_errors.md"), "w").write(md)
 
 
 if __name__ == "__main__":
