@@ -13,6 +13,7 @@
 // (frame split, bin, source).  The per-bin update kernel adds the nsplit partials in fp64.
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "oiva_device.h"
 #include "cov_arith.h"
@@ -355,6 +356,14 @@ hipError_t dispatch_kc(int kc, bool unit, Fn&& fn) {
         case 4:
             if constexpr (kRegs * 4 <= 144) return fn((CovKernel<ACC>)cov_kernel<M, 4, false, ACC>, 4);
             break;
+        // (round 5) one source more than the budget of 144 accumulator registers allows where that saves a pass over X on a
+        // short frame axis: 7 channels x 3 sources (147), 5 x 5 (125) -- see cov_sources_per_pass
+        case 3:
+            if constexpr (M == 7 && sizeof(ACC) == 4) return fn((CovKernel<ACC>)cov_kernel<M, 3, false, ACC>, 3);
+            break;
+        case 5:
+            if constexpr (M == 5 && sizeof(ACC) == 4) return fn((CovKernel<ACC>)cov_kernel<M, 5, false, ACC>, 5);
+            break;
     }
     return hipErrorInvalidValue;
 }
@@ -379,13 +388,23 @@ hipError_t dispatch_cov(int M, int kc, bool unit, Fn&& fn) {
 bool cov_supported(int M) { return M >= 1 && M <= OIVA_MAX_CHANNELS; }
 
 // sources handled per pass over X
-int cov_sources_per_pass(int M, int K, bool f64) {
+int cov_sources_per_pass(int M, int K, bool f64, bool short_axis) {
     if (f64 && cov_pair64_supported(M)) return cov_pair64_sources_per_pass(K);
     if (!f64 && cov_pair32_supported(M, K)) return cov_pair32_sources_per_pass();
     const int regs = M * M * (f64 ? 2 : 1);   // as many as fit the accumulator budget (KC * M^2 <= 144 registers)
     int kc = 1;
     if (K >= 2 && regs * 2 <= 144) kc = 2;
     if (K >= 3 && regs * 4 <= 144) kc = 4;
+    // 7 channels / 3+ sources and 5 / 5: a third / fifth source per pass (147 / 125 accumulators: two waves per SIMD instead of
+    // three, a pass of 7 channels 100 us instead of 75 at 2048 x 4000) where that saves a whole pass over X.  Measured (covariance
+    // pass, iteration): 2048 x 4000 x 7 / 3 162 -> 105 us (239 -> 198), 5 / 5 121 -> 93 (203 -> 181), 2049 x 235 x 7 / 3 22.0 ->
+    // 16.5 (51.8 -> 47.6), 7 / 7 34.0 -> 27.2 (73.8 -> 66.6); not 7 / 4 (two passes either way: 21.8 -> 23.4) and 7 / 7 only on
+    // a short frame axis (2048 x 4000: three passes of three 294 us, four of two 283).  $OIVA_COV_KC_WIDE=0: off.
+    static const bool wide = [] { const char* v = std::getenv("OIVA_COV_KC_WIDE"); return !(v && v[0] == '0'); }();
+    if (!f64 && wide) {
+        if (M == 7 && (K == 3 || K == 5 || K == 6 || (K == 7 && short_axis))) kc = 3;
+        if (M == 5 && K >= 5) kc = 5;
+    }
     return kc;
 }
 

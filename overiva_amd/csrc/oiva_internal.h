@@ -139,7 +139,7 @@ bool cov_half16_f64_supported(int M, int K);
 int cov_half16_f64_sources_per_pass(int K);
 hipError_t launch_cov_half16_f64(hipStream_t s, const float2* X, const float* R, float* Wt, float* wscale, int model, int raw,
                                  double* Vpart, int T, int F, int M, int Mv, int K, const CovGeom& g);
-int cov_sources_per_pass(int M, int K, bool f64);
+int cov_sources_per_pass(int M, int K, bool f64, bool short_axis = false);
 hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n);
 bool cov_supported(int M);
 

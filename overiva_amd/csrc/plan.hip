@@ -243,7 +243,7 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
     g.pair32 = !p->cov_f64() && cov_pair32_supported(p->M, p->K);
     const bool pair = g.pair32 || (p->cov_f64() && cov_pair64_supported(p->M));
     g.nbg = ceil_div(p->F, pair ? cov_pair64_bins_per_block() : kBinsPerWave);
-    g.kc = cov_sources_per_pass(p->M, p->K, p->cov_f64());
+    g.kc = cov_sources_per_pass(p->M, p->K, p->cov_f64(), p->T < 1024);
     const int nz = ceil_div(p->K, g.kc);
     int nsplit = nsplit_req;
     // few sources: the Hermitian half on the vector ALU, four lanes per (bin, frame).  One or two sources are one pass
