@@ -246,6 +246,9 @@ hipError_t launch_write_one(hipStream_t s, const float2* X, const float2* What, 
 }  // namespace
 
 int pow_sources_per_pass(int M, int K) {
+    // (round 5, measured and dropped: all of 5..8 sources in ONE pass, power_kernel<M, 8> -- 2049 x 235: 5 / 5 10.3 -> 11.7 us,
+    //  6 / 6 11.9 -> 12.8, 7 / 7 13.5 -> 14.5, 8 / 8 17.8 -> 18.9; 2048 x 4000: 8 / 8 121 -> 129, 5 / 5 75 -> 76, only 8 / 5
+    //  140 -> 111: eight demixing products per frame make the pass arithmetic-bound, two passes of four overlap)
     if (K >= 3) return 4;
     if (K >= 2) return 2;
     return 1;
