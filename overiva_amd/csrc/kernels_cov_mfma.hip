@@ -17,6 +17,11 @@ namespace {
 
 // Final weights w[t,k] = 1 / max(r[t,k] / gamma_k, eps) (overiva.py:158-173) for the matrix-core kernel, which
 // has no VALU slots to spare for the divide: one thread per (frame, padded source column).
+// (Round 5, measured and dropped: the table written by the activation kernel itself instead of this launch of 5-7 us -- by its
+//  last workgroup: one workgroup for 64 000 divisions, activation stage 4 -> 67-135 us; by the last workgroup of every SOURCE,
+//  column k of the table each: strided 4-byte stores and loads from 16 CUs into the same lines, 4 + 5 -> 17 us at 8 channels /
+//  2 sources in float64, 7 + 7 -> 50 at 16 / 16, equal (9.7 against 10.0) at 235 frames.  gamma needs every block of a source, so a
+//  row-major split would have to wait inside the kernel.)
 constexpr int kMaxK = OIVA_MAX_CHANNELS;
 __global__ __launch_bounds__(kBlock) void weights_kernel(const float* __restrict__ R, float* __restrict__ Wt,
                                                          float* __restrict__ wscale, int model, int raw, int T, int K,
