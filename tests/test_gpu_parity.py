@@ -133,6 +133,33 @@ def test_weighted_covariance(oa, golden, splits, mode):
     assert np.array_equal(V, np.conj(np.swapaxes(V, -1, -2)))
 
 
+@pytest.mark.parametrize("shape", [(1024, 6, 8, 2), (1024, 5, 5, 5), (1024, 4, 7, 3), (1024, 3, 8, 4), (1024, 3, 4, 2), (1024, 2, 12, 3)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+def test_update_adds_any_number_of_frame_splits(oa, shape):
+    """the per-bin update kernels add the frame splits' partial covariances in batches of 2, 4, 8 or 16 loads that follow the number
+    of splits (csrc/oiva_internal.h::sum_vpart, round 5; more than 16: several rounds): every batch size and the multi-round case,
+    two iterations from the identity against the oracle (overiva.py:176-190) -- update_bg (8 / 2, 4 / 2), update_det (5 / 5),
+    update_gram (7 / 3, 8 / 4), one wavefront per bin (12 / 3)"""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F, M, seed=41)
+    _, Wref = orc.overiva_faithful(X.astype(np.complex128), n_src=K, n_iter=2, proj_back=False, model="laplace", return_filters=True)
+    seen = set()
+    for splits in (1, 2, 3, 4, 6, 8, 12, 16, 22, 32):
+        with oa.Plan(T, F, M, K, "laplace") as p:
+            p.set_precision("mixed")
+            p.set_resident(False)
+            p.set_cov_splits(splits)
+            p.set_x(X)
+            p.covariance()
+            p.set_w(None)
+            p.iterate(2)
+            W = p.get_w()
+            got = p.cov_splits()
+        seen.add(0 if got <= 2 else 1 if got <= 4 else 2 if got <= 8 else 3 if got <= 16 else 4)
+        assert orc.rel_err(W, Wref) < 3e-6, (splits, got)
+    assert seen == {0, 1, 2, 3, 4} or M > 8, seen      # (every batch size and more than one round of 16; 9..16 channels: own loader)
+
+
 def test_demix_power(oa, golden):
     X, K = golden["X"], int(golden["K"])
     T, F, M = X.shape
