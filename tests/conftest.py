@@ -105,8 +105,8 @@ def c64_jitter(g, model, n_iter):
 
 def c64_diverged(g, model, n_iter):
     """True when the reference's OWN complex64 run is not reproducible to 1e-3 under a last-bit change of its input (measured
-    on the reference, c64_jitter above): the complex64 counterpart of `chaotic`.  Three non-chaotic rows: e_mix laplace 20
-    (jitter 7.1e-3, floor 1.8e-3), l_mix gauss 5 (6.1e-3 / 3.7e-3), w_mix gauss 20 (5.7e-3 / 2.7e-3).  On such a row the
+    on the reference, c64_jitter above): the complex64 counterpart of `chaotic`.  Four non-chaotic rows: e_mix laplace 20
+    (jitter 7.1e-3, floor 1.8e-3), l_mix gauss 5 (6.1e-3 / 3.7e-3), w_mix gauss 20 (5.7e-3 / 2.7e-3), v_mix gauss 20 (2.2e-3).  On such a row the
     distance from the reference's complex64 result is held to its jitter instead of its floor."""
     j = c64_jitter(g, model, n_iter)
     return j is not None and j > JITTER_LIMIT

@@ -13,7 +13,7 @@ STFT input; the distance is ||a-b||_F / ||b||_F.
     against the reference's OWN complex64 result (``W_c64_*``): ``max(1e-5, 1.5 * floor)`` with floor = distance between
     the reference's complex64 and complex128 results -- the parity claim -- and against the complex128 result
     ``max(that bound, floor)``: never less accurate than the reference's own complex64 arithmetic (achieved: 0.1-0.9
-    floors).  On the three rows where the reference's own complex64 run is not reproducible to 1e-3 under a last-bit change
+    floors).  On the four rows where the reference's own complex64 run is not reproducible to 1e-3 under a last-bit change
     of X (conftest.c64_diverged, measured on the real reference: tests/golden/c64_jitter.npz) "floor" is replaced by that
     jitter where it is larger -- see test_overiva_matches_reference.  One row (NOISE_ROWS_OVER_ONE_FLOOR: i.i.d. input,
     gauss, 20 iterations, a row of pure amplified rounding noise, where the reference's complex128-formed covariances beat
@@ -341,7 +341,7 @@ def test_overiva_matches_reference(oa, golden, model, n_iter, dt):
     from overiva_amd.overiva import resolve_precision
 
     mode = resolve_precision(Xin.dtype, X.shape[2], n_src=K)
-    # One floor against the complex128 result, 1.5 against the complex64 one -- everywhere but on the three rows where the
+    # One floor against the complex128 result, 1.5 against the complex64 one -- everywhere but on the four rows where the
     # reference's OWN complex64 run is not reproducible to 1e-3 (conftest.c64_diverged: its W moves by `jitter` when X changes
     # in the last bit; e_mix laplace 20: jitter 7.1e-3 = 4 floors).  There the yardstick is that jitter: nothing can be pinned
     # on a result tighter than the result pins itself.
