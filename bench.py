@@ -282,12 +282,15 @@ def _cov_roofline(shape, mode, cov_ms, fused=False):
         # (64 lanes x 2 flop slots); bound by fp32 arithmetic -- matrix and vector instructions share the 157.3 TFLOP/s ALUs
         bytes_cov = cov_algorithmic_bytes(t, f, m, k)
         mfma = (16 if mc == 16 else mc + 1) * 2048.0 / 4 * t * f
-        valu = (2 + 4 * (mc // 2)) * 128.0 / 4 * t * f
+        pk = mc == 16 and os.environ.get("OIVA_HMFMA_PK", "1") != "0"
+        # (16 channels, round 5: the partners from LDS, a product pair = two PACKED instructions of 256 flop slots -- 2 + 4 plain
+        #  instructions for the diagonal and the shared group of distance 8, 14 packed ones -- instead of 34 plain ones of 128)
+        valu = ((6 * 128.0 + 14 * 256.0) if pk else (2 + 4 * (mc // 2)) * 128.0) / 4 * t * f
         issued = mfma + valu
         useful = ((m * (m - 1) // 2) * (6.0 + 4.0 * k) + m * (3.0 + 2.0 * k)) * t * f     # Hermitian half, products formed once
         naive = 8.0 * k * m * m * t * f                         # naive complex count (268.4 GF at 16 x 16)
         sec = cov_ms * 1e-3
-        kname = f"cov_hmfma_kernel<{'true' if mc == 16 else 'false'}, true>"
+        kname = f"cov_hmfma_kernel<{'true' if mc == 16 else 'false'}, true, {'true' if pk else 'false'}>"
         return kname, {"bound": "fp32", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, the sources on the fp32 matrix cores, overiva.py:179)",
                        "achieved": issued / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
                        "issued_flops_per_launch": issued, "issued_matrix_flops_per_launch": mfma, "issued_vector_flops_per_launch": valu,

@@ -42,6 +42,8 @@ constexpr int kHmStage = kHmX + 512;                    // + 2 x 64 weights
 constexpr int kHmChunk = 32;                            // accumulators per LDS round of the epilogue: 4 groups x 2 sets x 4 (5 rounds for 17 groups)
 constexpr int kHmLdsStride = kBlock + 1;
 constexpr int kHmWeightStride = 16;                     // row stride of the weight table (launch_cov_weights)
+constexpr int kWtHalf = 4 * kHmFrames * kHmWeightStride * 4;      // bytes of the weight table between a frame and the one 16 later
+static_assert(kWtHalf <= kHmX + 256, "the LDS base shifted by it stays inside the stage");
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
@@ -102,7 +104,7 @@ using hm_ic = std::integral_constant<int, I>;
 // lane's offset is a constant, frames past the end read as zero by the descriptor's range check: no vector instruction for
 // addresses (the flat form spent 21 per stage on them, three at a quarter of the rate; on this chip vector and matrix
 // instructions share the ALUs and their times add).  Needs a split's frames + 35 within 4 GB of X; else the flat form.
-template <bool M16, bool BUF>
+template <bool M16, bool BUF, bool PK>
 __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __restrict__ X, const float* __restrict__ Wt,
                                                               double* __restrict__ Vpart, int T, int F, int M, int Mv, int K, int tc) {
     constexpr int NG = M16 ? 16 : 17;
@@ -133,7 +135,10 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     //      the wave's frame n = 8 i + q, the half-1 frame n = 8 i + 4 + q (16 frames later).  The weights of the same frames:
     //      lane l moves Wt[frame of slot l >> 4][source l & 15], once per half (frames past the split: the zeroed row T).
     char* wring = reinterpret_cast<char*>(ring) + wave * (kHmStages * kHmStage);       // wave-uniform
-    const int half = (lane >> 3) & 1;
+    // (PK: the frames of a stage lie set-major, 128 bytes each -- lane l moves piece l & 7 of frame (l >> 3) & 3 of set l >> 5 --, so
+    //  that the four frames of an operand read fall into two bank groups instead of one: see stage_pk below)
+    const int half = PK ? lane >> 5 : (lane >> 3) & 1;
+    const int qd = PK ? (lane >> 3) & 3 : q;              // frame slot of the lane's DMA piece
     const unsigned piece_off = (unsigned)min(lane & 7, M / 2 - 1) * 16u;
     const char* xbytes = reinterpret_cast<const char*>(X);
     const size_t row_bytes = (size_t)F * M * 8;
@@ -141,9 +146,8 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     // (buffer form) the workgroup's bin at the first frame of its split is offset 0 of stage 0's descriptor; a stage is 32 frames
     const unsigned row32 = (unsigned)row_bytes;            // (the launch checks 36 rows < 4 GB)
     const unsigned col_off = (unsigned)f0 * (unsigned)M * 8u;
-    const unsigned xvoff = (unsigned)(wave + 4 * q + 16 * half) * row32 + piece_off;
+    const unsigned xvoff = (unsigned)(wave + 4 * qd + 16 * half) * row32 + piece_off;
     const unsigned wvoff0 = (unsigned)((wave + 4 * q) * kHmWeightStride + n) * 4u;
-    const unsigned wvoff1 = wvoff0 + 4u * kHmFrames * kHmWeightStride * 4u;
     auto issue = [&](int i, auto sc) {
         constexpr int s = decltype(sc)::value;
         char* dst = wring + s * kHmStage;
@@ -170,10 +174,13 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
             const int tw = min(t_begin + 8 * kHmFrames * i, T);
             const auto wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt + (size_t)tw * kHmWeightStride), 0, (T - tw) * kHmWeightStride * 4, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lvoid_t*)(dst + kHmX), 4, (int)wvoff0, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lvoid_t*)(dst + kHmX + 256), 4, (int)wvoff1, 0, 0, 0);
+            // (the second half's weights 16 frames = 1 KB further in the table: as the instruction's immediate offset, which moves
+            //  the LDS address by as much -- so the LDS base is handed over 1 KB short; one address register less, which is what
+            //  keeps the PK form at three waves per SIMD)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lvoid_t*)(dst + kHmX + 256 - kWtHalf), 4, (int)wvoff0, 0, kWtHalf, 0);
         } else {
             const int t0 = t_begin + wave + 4 * (2 * kHmFrames * i + q), t1 = t0 + 4 * kHmFrames;
-            const int tx = half ? t1 : t0;
+            const int tx = t_begin + wave + 4 * (2 * kHmFrames * i + qd) + (half ? 4 * kHmFrames : 0);
             const int tcl = min(i < nstages ? tx : T - 1, T - 1);
             __builtin_amdgcn_global_load_lds((gvoid_t*)(run0 + (size_t)tcl * row_bytes), (lvoid_t*)dst, 16, 0, 0);
             const int tw0 = (i < nstages && t0 < t_end) ? t0 : T, tw1 = (i < nstages && t1 < t_end) ? t1 : T;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     // ---- operand addresses of this lane inside a frame slot of set 0 of stage 0 (set 1 at + 128 bytes, stage s at + s stages):
     //      its own channel, then the channels (n + c) mod M; lanes n >= M (fewer than 16 channels) read channel 0 and produce
     //      entries that are dropped
-    const unsigned lbase = (unsigned)(uintptr_t)wring + (unsigned)(q * kHmSlot);
+    const unsigned lbase = (unsigned)(uintptr_t)wring + (unsigned)(q * (PK ? kHmSlot / 2 : kHmSlot));
     const int nn = n < M ? n : 0;
     unsigned ax[9];
     ax[0] = lbase + 8u * (unsigned)nn;
@@ -254,6 +261,128 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
         groups(o1, w1, acc[1]);
     };
 
+    // PK (16 channels): the partners of the products come from LDS -- one ds_read_b64 per pair distance at the lane's rotated
+    // address -- and a product pair (re, im) is TWO packed instructions (v_pk_mul_f32 / v_pk_fma_f32 with op_sel: cov_arith.h)
+    // instead of four DPP ones: 20 vector instructions per accumulator set (2 for the diagonal, 4 for the shared group of distance
+    // 8, 2 x 7) instead of 34 beside its 16 matrix instructions.  Same operations in the same order: same bits.  The frames of a
+    // stage lie set-major, 128 bytes each: lane (q, n) reads byte 128 q + 8 ((n + c) mod 16) of its set -- 32 different 8-byte
+    // bank pairs, each hit by two of the four frames, the minimum of a 64-lane 8-byte read (frame slots of 256 bytes put all four
+    // frames on the same banks: four passes).  Reads in batches of at most six, issued two batches ahead of their use, counted
+    // lgkmcnt waits; the products run one group ahead of the matrix instructions that read them (a matrix instruction must not
+    // directly follow the asm block that writes its operand), pinned by scheduling barriers.
+    constexpr int kPkSet = 512;
+    auto rd64 = [&](unsigned addr, auto off) {
+        v2f r;
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(decltype(off)::value) : "memory");
+        return r;
+    };
+    auto rd32 = [&](unsigned addr, auto off) {
+        float r;
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(decltype(off)::value) : "memory");
+        return r;
+    };
+    auto prod = [&](v2f row, v2f part) {
+        v2f p = qk_mul_lo_negim(row, part);
+        qk_fma_hi_swap(row, part, p);
+        return p;
+    };
+    auto mm = [&](f32x4& a, float w, float b) { a = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b, a, 0, 0, 0); };
+    // diagonal + distance 8 (its two parts in one group, by DPP) + distances 1 .. 4 of one set; pa: the partners 1 .. 4
+    auto set_first = [&](v2f row, float w, const v2f (&pa)[4], f32x4 (&a)[NG]) {
+        float both8;
+        asm volatile("v_mul_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                     "v_mul_f32_dpp %0, -%1, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                     "v_fmac_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                     "v_fmac_f32_dpp %0, %2, %1 row_ror:8 row_mask:0xf bank_mask:0xc"
+                     : "=&v"(both8)
+                     : "v"(row.x), "v"(row.y));
+        const v2f p1 = prod(row, pa[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a[0], w, fmaf(row.y, row.y, row.x * row.x));
+        mm(a[15], w, both8);
+        const v2f p2 = prod(row, pa[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a[1], w, p1.x);
+        mm(a[2], w, p1.y);
+        const v2f p3 = prod(row, pa[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a[3], w, p2.x);
+        mm(a[4], w, p2.y);
+        const v2f p4 = prod(row, pa[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a[5], w, p3.x);
+        mm(a[6], w, p3.y);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a[7], w, p4.x);
+        mm(a[8], w, p4.y);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // distances 5 .. 7
+    auto set_second = [&](v2f row, float w, const v2f (&pb)[3], f32x4 (&a)[NG]) {
+        const v2f p5 = prod(row, pb[0]);
+        const v2f p6 = prod(row, pb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a[9], w, p5.x);
+        mm(a[10], w, p5.y);
+        const v2f p7 = prod(row, pb[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a[11], w, p6.x);
+        mm(a[12], w, p6.y);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a[13], w, p7.x);
+        mm(a[14], w, p7.y);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage_pk = [&](auto sc) {
+        constexpr int so = decltype(sc)::value * kHmStage;
+        using O0 = hm_ic<so>;
+        using O1 = hm_ic<so + kPkSet>;
+        // batch A: weight, own sample and partners 1 .. 4 of set 0, behind the counted wait for the stage's three DMAs
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (kHmStages - 1)) : "memory");
+        const float w0 = rd32(a_w, hm_ic<so + kHmX>{});
+        const v2f r0 = rd64(ax[0], O0{});
+        v2f pa[4], pb[3];
+        pa[0] = rd64(ax[1], O0{});
+        pa[1] = rd64(ax[2], O0{});
+        pa[2] = rd64(ax[3], O0{});
+        pa[3] = rd64(ax[4], O0{});
+        // batch B: partners 5 .. 7 of set 0, weight and own sample of set 1
+        pb[0] = rd64(ax[5], O0{});
+        pb[1] = rd64(ax[6], O0{});
+        pb[2] = rd64(ax[7], O0{});
+        const float w1 = rd32(a_w, hm_ic<so + kHmX + 256>{});
+        const v2f r1 = rd64(ax[0], O1{});
+        asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");       // batch A has arrived (LDS reads return in order)
+        __builtin_amdgcn_sched_barrier(0);
+        set_first(r0, w0, pa, acc[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // batch B
+        __builtin_amdgcn_sched_barrier(0);
+        // batch C: partners 1 .. 4 of set 1 (into the registers set 0 has finished with)
+        v2f qa[4], qb[3];
+        qa[0] = rd64(ax[1], O1{});
+        qa[1] = rd64(ax[2], O1{});
+        qa[2] = rd64(ax[3], O1{});
+        qa[3] = rd64(ax[4], O1{});
+        __builtin_amdgcn_sched_barrier(0);
+        set_second(r0, w0, pb, acc[0]);
+        // batch D: partners 5 .. 7 of set 1
+        qb[0] = rd64(ax[5], O1{});
+        qb[1] = rd64(ax[6], O1{});
+        qb[2] = rd64(ax[7], O1{});
+        asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");       // batch C
+        __builtin_amdgcn_sched_barrier(0);
+        set_first(r1, w1, qa, acc[1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // batch D
+        __builtin_amdgcn_sched_barrier(0);
+        set_second(r1, w1, qb, acc[1]);
+    };
+    auto run_stage = [&](auto sc) {
+        if constexpr (PK)
+            stage_pk(sc);
+        else
+            stage(sc);
+    };
+
     // the ring of four stages unrolled: stage i sits in slot i mod 4, its successor i + 3 is requested before it is consumed
     // (every stage of the loop requests exactly three DMAs -- the counted wait of the first read depends on it; requests past
     //  the split's last stage land in slots nobody reads)
@@ -263,27 +392,27 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     int i = 0;
     for (; i + 4 <= nstages; i += 4) {
         issue(i + 3, hm_ic<3>{});
-        stage(hm_ic<0>{});
+        run_stage(hm_ic<0>{});
         issue(i + 4, hm_ic<0>{});
-        stage(hm_ic<1>{});
+        run_stage(hm_ic<1>{});
         issue(i + 5, hm_ic<1>{});
-        stage(hm_ic<2>{});
+        run_stage(hm_ic<2>{});
         issue(i + 6, hm_ic<2>{});
-        stage(hm_ic<3>{});
+        run_stage(hm_ic<3>{});
     }
     if (i < nstages) {
         issue(i + 3, hm_ic<3>{});
-        stage(hm_ic<0>{});
+        run_stage(hm_ic<0>{});
         ++i;
     }
     if (i < nstages) {
         issue(i + 3, hm_ic<0>{});
-        stage(hm_ic<1>{});
+        run_stage(hm_ic<1>{});
         ++i;
     }
     if (i < nstages) {
         issue(i + 3, hm_ic<1>{});
-        stage(hm_ic<2>{});
+        run_stage(hm_ic<2>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the DMA queue before the ring becomes reduction scratch
 
@@ -554,12 +683,17 @@ hipError_t launch_cov_hmfma(hipStream_t s, const float2* X, const float* Wt, dou
     // ($OIVA_HMFMA_FLAT=1, read at every launch: the flat form whatever the size -- tests compare the two bit for bit)
     const char* flat = std::getenv("OIVA_HMFMA_FLAT");
     const bool buf = !(flat && flat[0] == '1') && (size_t)36 * F * M * 8 < 0xffffffffull;
+    // ($OIVA_HMFMA_PK=0: the partners by DPP rotations of the lane's own operand, four vector instructions per product pair)
+    const char* pkv = std::getenv("OIVA_HMFMA_PK");
+    const bool pk = !(pkv && pkv[0] == '0');
     if (M == 16) {
-        if (buf) return launch_dominant(cov_hmfma_kernel<true, true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
-        return launch_dominant(cov_hmfma_kernel<true, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+        if (buf && pk) return launch_dominant(cov_hmfma_kernel<true, true, true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+        if (buf) return launch_dominant(cov_hmfma_kernel<true, true, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+        if (pk) return launch_dominant(cov_hmfma_kernel<true, false, true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+        return launch_dominant(cov_hmfma_kernel<true, false, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
     }
-    if (buf) return launch_dominant(cov_hmfma_kernel<false, true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
-    return launch_dominant(cov_hmfma_kernel<false, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+    if (buf) return launch_dominant(cov_hmfma_kernel<false, true, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+    return launch_dominant(cov_hmfma_kernel<false, false, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
 }
 
 }  // namespace oiva

@@ -253,8 +253,11 @@ def test_matrix_core_kernel_ring_tails_and_both_forms_of_its_loads(oa, shape, mo
     ref = orc.weighted_cov_all(X, rinv.astype(np.float64))
     for splits in (1, 0):
         V = {}
-        for flat in ("0", "1"):
+        # (flat, pk): the loads flat or buffer-form; at 16 channels the partners of the products from LDS with packed products
+        # ($OIVA_HMFMA_PK, default) or by DPP rotations -- four forms of one arithmetic
+        for flat, pk in (("0", "1"), ("1", "1"), ("0", "0"), ("1", "0")):
             monkeypatch.setenv("OIVA_HMFMA_FLAT", flat)
+            monkeypatch.setenv("OIVA_HMFMA_PK", pk)
             with oa.Plan(T, F, M, K, "laplace") as p:
                 p.set_precision("mixed")
                 if splits:
@@ -263,10 +266,10 @@ def test_matrix_core_kernel_ring_tails_and_both_forms_of_its_loads(oa, shape, mo
                 p.covariance()
                 p.t_set_rinv(rinv)
                 p.t_run_weighted_cov()
-                V[flat] = p.t_get_v(np.complex128)
-        assert np.array_equal(V["0"], V["1"])
-        assert orc.rel_err(V["0"], ref) < (2e-5 if splits == 1 and T > 2000 else 3e-6)
-        assert np.array_equal(V["0"], np.conj(np.swapaxes(V["0"], -1, -2)))
+                V[flat + pk] = p.t_get_v(np.complex128)
+        assert np.array_equal(V["01"], V["11"]) and np.array_equal(V["01"], V["00"]) and np.array_equal(V["01"], V["10"])
+        assert orc.rel_err(V["01"], ref) < (2e-5 if splits == 1 and T > 2000 else 3e-6)
+        assert np.array_equal(V["01"], np.conj(np.swapaxes(V["01"], -1, -2)))
 
 
 @pytest.mark.parametrize("shape", [(400, 6, 16, 16), (333, 5, 16, 9), (180, 3, 15, 15), (70, 2, 16, 12)])
