@@ -281,9 +281,14 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
         asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(decltype(off)::value) : "memory");
         return r;
     };
+    // (re, im) of row conj(part): (row.x part.x, -(row.x part.y)), then += (row.y part.y, row.y part.x) -- qk_mul_lo_negim and
+    // qk_fma_hi_swap of cov_arith.h as ONE statement (hipcc puts a wait state between two asm statements that share a register)
     auto prod = [&](v2f row, v2f part) {
-        v2f p = qk_mul_lo_negim(row, part);
-        qk_fma_hi_swap(row, part, p);
+        v2f p;
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+                     "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+                     : "=&v"(p)
+                     : "v"(row), "v"(part));
         return p;
     };
     auto mm = [&](f32x4& a, float w, float b) { a = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b, a, 0, 0, 0); };
