@@ -14,7 +14,7 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "liboveriva_hip.so")
-SOURCES = ["plan.hip", "host_io.hip", "kernels_cov.hip", "kernels_cov_mfma.hip", "kernels_cov_quad.hip", "kernels_cov_half16.hip", "kernels_cov_hmfma.hip", "kernels_cov_pair64.hip", "kernels_cov_pair32.hip", "kernels_demix.hip", "kernels_power_mfma.hip", "kernels_update.hip", "kernels_cov_update.hip", "kernels_update16.hip", "kernels_misc.hip", "kernels_ogive.hip", "kernels_evd.hip", "exchange.hip", "stft.hip", "resident.hip", "kernels_resident_m4.hip", "kernels_resident_m8.hip", "kernels_resident_m6.hip", "kernels_resident_m2.hip"]
+SOURCES = ["plan.hip", "host_io.hip", "kernels_cov.hip", "kernels_cov_mfma.hip", "kernels_cov_quad.hip", "kernels_cov_half16.hip", "kernels_cov_hmfma.hip", "kernels_cov_pair64.hip", "kernels_cov_pair32.hip", "kernels_demix.hip", "kernels_power_mfma.hip", "kernels_update.hip", "kernels_cov_update.hip", "kernels_update16.hip", "kernels_update16r.hip", "kernels_misc.hip", "kernels_ogive.hip", "kernels_evd.hip", "exchange.hip", "stft.hip", "resident.hip", "kernels_resident_m4.hip", "kernels_resident_m8.hip", "kernels_resident_m6.hip", "kernels_resident_m2.hip"]
 HEADERS = [os.path.join(CSRC, "oiva_internal.h"), os.path.join(CSRC, "oiva_device.h"), os.path.join(CSRC, "update_chain.h"), os.path.join(CSRC, "cov_arith.h"), os.path.join(CSRC, "demix_arith.h"), os.path.join(CSRC, "resident.h"), os.path.join(CSRC, "host_io.h"), os.path.join(CSRC, "resident_kernel.inc"), os.path.join(REPO, "include", "overiva_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]

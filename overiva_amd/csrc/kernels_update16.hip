@@ -712,6 +712,7 @@ __global__ __launch_bounds__(64) void update_det16_kernel(UpdateArgs a) {
 }  // namespace
 
 hipError_t launch_update_wave16(hipStream_t s, const UpdateArgs& a) {
+    if (update_det16r_applies(a)) return launch_update_det16r(s, a);       // (round 6; $OIVA_DET16_ROWS=0: the kernels below)
     dim3 grid(a.F);
     auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(64), 0, s, a); };
     const bool over = a.K < a.M;

@@ -256,6 +256,9 @@ hipError_t launch_update(hipStream_t s, const UpdateArgs& a);
 bool cov_update_supported(int M, int K, int T, int F, int nsplit, int tc);
 hipError_t launch_cov_update(hipStream_t s, const float2* X, const float* R, float* wscale, int model, const UpdateArgs& a, int tc);
 hipError_t launch_update_wave16(hipStream_t s, const UpdateArgs& a);   // 9..16 channels, one wavefront per bin
+// determined float64 update of 9..16 channels, one matrix row per lane and four bins per wavefront (kernels_update16r.hip)
+bool update_det16r_applies(const UpdateArgs& a);
+hipError_t launch_update_det16r(hipStream_t s, const UpdateArgs& a);
 
 // Epilogue, overiva.py:192-199.
 //   stats: per-bin sums for projection back: [nsplit][F][K][3] = (Re num, Im num, den)

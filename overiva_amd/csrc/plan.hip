@@ -81,6 +81,33 @@ size_t pool_cap_bytes() {
     }();
     return cap;
 }
+// every buffer the pool holds goes back to the driver (oiva_pool_trim; dev_malloc when the driver is out of memory)
+void pool_release_all() {
+    BigPool& bp = big_pool();
+    std::lock_guard<std::mutex> g(bp.m);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (auto& e : bp.held) {
+        (void)hipSetDevice(e.dev);
+        (void)hipFree(e.p);
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    bp.held.clear();
+    bp.total = 0;
+}
+// hipMalloc of the library: the pool's idle buffers are memory the caller thinks is free, so before an allocation fails for
+// want of memory they are handed back and the allocation is tried once more
+hipError_t dev_malloc(void** out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    (void)hipGetLastError();
+    pool_release_all();
+    return hipMalloc(out, bytes);
+}
+template <class P>
+hipError_t dev_malloc(P** out, size_t bytes) {
+    return dev_malloc(reinterpret_cast<void**>(out), bytes);
+}
 hipError_t big_alloc(int dev, void** out, size_t bytes) {
     if (bytes >= kPoolMinBytes) {
         BigPool& bp = big_pool();
@@ -93,7 +120,7 @@ hipError_t big_alloc(int dev, void** out, size_t bytes) {
                 return hipSuccess;
             }
     }
-    return hipMalloc(out, bytes);
+    return dev_malloc(out, bytes);
 }
 void big_free(int dev, void* ptr, size_t bytes) {
     if (!ptr) return;
@@ -410,7 +437,7 @@ int ensure_vpart(oiva_plan* p) {
     if (p->cov.nsplit > p->vpart_splits_alloc) {
         if (p->Vpart) HIP_TRY(hipFree(p->Vpart));
         p->Vpart = nullptr;
-        HIP_TRY(hipMalloc(&p->Vpart, (vpart_floats(p, p->cov.nsplit) + 2) * sizeof(double)));   // either element type; sum_vpart reads idx + 1
+        HIP_TRY(dev_malloc(&p->Vpart, (vpart_floats(p, p->cov.nsplit) + 2) * sizeof(double)));   // either element type; sum_vpart reads idx + 1
         p->vpart_splits_alloc = p->cov.nsplit;
     }
     return OIVA_OK;
@@ -518,10 +545,10 @@ int resident_alloc(oiva_plan* p) {
     const size_t b_flags = up((16 + (size_t)g.NB * g.NS) * sizeof(unsigned));      // ctrl words, then the XCD table
     const size_t b_stamps = up((size_t)kResidentStampIters * kResidentStamps * sizeof(unsigned long long));
     const size_t total = b_parts + b_psum + b_vpart + b_rsum + b_wpub + b_flags + b_stamps;
-    if (!p->res_what) HIP_TRY(hipMalloc(&p->res_what, (size_t)p->F * NA * sizeof(float2)));
-    if (!p->res_what64) HIP_TRY(hipMalloc(&p->res_what64, (size_t)p->F * NA * sizeof(double2)));
+    if (!p->res_what) HIP_TRY(dev_malloc(&p->res_what, (size_t)p->F * NA * sizeof(float2)));
+    if (!p->res_what64) HIP_TRY(dev_malloc(&p->res_what64, (size_t)p->F * NA * sizeof(double2)));
     if (!p->res_code_host) HIP_TRY(hipHostMalloc((void**)&p->res_code_host, sizeof(unsigned), hipHostMallocDefault));
-    HIP_TRY(hipMalloc(&p->res_block, total));
+    HIP_TRY(dev_malloc(&p->res_block, total));
     HIP_TRY(hipMemsetAsync(p->res_block, 0, total, p->stream));
     char* c = static_cast<char*>(p->res_block);
     p->res_parts = reinterpret_cast<float*>(c);
@@ -570,7 +597,7 @@ int run_resident(oiva_plan* p, int n, bool* ran) {
         const size_t bytes = (size_t)g.NB * g.NS * n * kResidentStamps * sizeof(unsigned long long);
         if (p->res_trace_buf) HIP_TRY(hipFree(p->res_trace_buf));
         p->res_trace_buf = nullptr;
-        HIP_TRY(hipMalloc(&p->res_trace_buf, bytes));
+        HIP_TRY(dev_malloc(&p->res_trace_buf, bytes));
         HIP_TRY(hipMemsetAsync(p->res_trace_buf, 0, bytes, p->stream));
         a.stamps = p->res_trace_buf;
         a.stamp_all = 1;
@@ -787,7 +814,7 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     if (M > 8 && M % 2 == 1) {
         // 9 / 11 / 13 / 15 channels: the vector-ALU covariance kernels read 16-byte pieces at an even channel pitch, so
         // they get their own copy of X with one zero channel per bin (filled by oiva_plan_covariance; + (M + 1) / M of X)
-        hipError_t ep = hipMalloc((void**)&p->X_pad, (size_t)T * F * (M + 1) * sizeof(float2));
+        hipError_t ep = dev_malloc((void**)&p->X_pad, (size_t)T * F * (M + 1) * sizeof(float2));
         if (ep != hipSuccess) {
             oiva_plan_destroy(p);
             return fail(OIVA_ERR_HIP, std::string("allocation of the padded copy of X failed: ") + hipGetErrorString(ep));
@@ -807,7 +834,7 @@ int oiva_plan_create(oiva_plan** out, int device, int T, int F, int M, int K, in
     const size_t nFMM = (size_t)F * M * M;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** ptr, size_t bytes) {
-        if (e == hipSuccess) e = hipMalloc(ptr, bytes);
+        if (e == hipSuccess) e = dev_malloc(ptr, bytes);
     };
     alloc((void**)&p->What, nFMM * sizeof(float2));
     alloc((void**)&p->What64, nFMM * sizeof(double2));
@@ -1078,7 +1105,11 @@ int oiva_plan_iterate(oiva_plan* p, int n) {
             HIP_TRY(hipGraphLaunch(g, p->stream));
             left -= m;
         }
+        // the host-side flags after n iterations, whether the graph was captured now (capturing runs stage_update, which sets
+        // them) or taken from the cache (nothing runs on the host): the float32 update leaves the complex128 copy behind
         p->wscale_pending = false;
+        p->raw_weights = 0;
+        p->what64_valid = p->upd_f64();
         return OIVA_OK;
     }
     for (int i = 0; i < n; ++i)
@@ -1104,7 +1135,7 @@ int oiva_plan_power_buffer(oiva_plan* p, int parts_per_rank, void** parts_dev, l
         if (rc) return rc;
         if (p->Ppart) HIP_TRY(hipFree(p->Ppart));
         p->Ppart = nullptr;
-        HIP_TRY(hipMalloc(&p->Ppart, part * parts_per_rank));
+        HIP_TRY(dev_malloc(&p->Ppart, part * parts_per_rank));
         // parts beyond nb stay zero; on the plan's own stream, so that it is ordered before the next power pass
         HIP_TRY(hipMemsetAsync(p->Ppart, 0, part * parts_per_rank, p->stream));
         p->ppart_alloc = parts_per_rank;
@@ -1169,7 +1200,7 @@ static int demix_to_host(oiva_plan* p, void* Y_host, long long row_pitch_bytes, 
         }
         const int slab = (int)std::max<size_t>(1, std::min<size_t>((size_t)p->T, ((size_t)256 << 20) / row));
         double2* stage = nullptr;
-        HIP_TRY(hipMalloc(&stage, row * slab));
+        HIP_TRY(dev_malloc(&stage, row * slab));
         hipError_t e = hipSuccess;
         for (int t0 = 0; t0 < p->T && e == hipSuccess; t0 += slab) {
             const int nt = std::min(slab, p->T - t0);
@@ -1193,10 +1224,21 @@ static int demix_to_host(oiva_plan* p, void* Y_host, long long row_pitch_bytes, 
     }
     if (c128 && p->io_c128_bytes < slab_bytes) {
         HIP_TRY(hipStreamSynchronize(p->stream));
+        // all three or none: the recorded size is that of every non-null slot, also after a failed allocation
         for (auto& b : p->io_c128) {
             big_free(p->device, b, p->io_c128_bytes);
             b = nullptr;
-            HIP_TRY(big_alloc(p->device, (void**)&b, slab_bytes));
+        }
+        p->io_c128_bytes = 0;
+        for (auto& b : p->io_c128) {
+            hipError_t e = big_alloc(p->device, (void**)&b, slab_bytes);
+            if (e != hipSuccess) {
+                for (auto& c : p->io_c128) {
+                    if (c) (void)hipFree(c);
+                    c = nullptr;
+                }
+                HIP_TRY(e);
+            }
         }
         p->io_c128_bytes = slab_bytes;
     }
@@ -1214,10 +1256,9 @@ static int demix_to_host(oiva_plan* p, void* Y_host, long long row_pitch_bytes, 
         HIP_TRY(host_ring_slots(slab_bytes, pinned));
     }
     auto finish = [&](hipError_t e) -> int {
-        if (registered) {
-            (void)hipStreamSynchronize(p->io_stream);
-            (void)hipHostUnregister(Y_host);
-        }
+        // nothing of this call is in flight when the ring (io_mutex) passes to the next caller, also after an error
+        (void)hipStreamSynchronize(p->io_stream);
+        if (registered) (void)hipHostUnregister(Y_host);
         if (e != hipSuccess) return fail(OIVA_ERR_HIP, std::string("final demix: ") + hipGetErrorString(e));
         return OIVA_OK;
     };
@@ -1266,17 +1307,7 @@ static int demix_to_host(oiva_plan* p, void* Y_host, long long row_pitch_bytes, 
 }
 
 int oiva_pool_trim(void) {
-    BigPool& bp = big_pool();
-    std::lock_guard<std::mutex> g(bp.m);
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    for (auto& e : bp.held) {
-        (void)hipSetDevice(e.dev);
-        (void)hipFree(e.p);
-    }
-    if (prev >= 0) (void)hipSetDevice(prev);
-    bp.held.clear();
-    bp.total = 0;
+    pool_release_all();
     return OIVA_OK;
 }
 
@@ -1348,8 +1379,8 @@ int oiva_plan_save_w(oiva_plan* p) {
     NEED(p->have_w, OIVA_ERR_STATE, "demixing matrix not set");
     DeviceGuard guard(p->device);
     const size_t n = (size_t)p->F * p->M * p->M;
-    if (!p->ck_what) HIP_TRY(hipMalloc((void**)&p->ck_what, n * sizeof(float2)));
-    if (!p->ck_what64) HIP_TRY(hipMalloc((void**)&p->ck_what64, n * sizeof(double2)));
+    if (!p->ck_what) HIP_TRY(dev_malloc((void**)&p->ck_what, n * sizeof(float2)));
+    if (!p->ck_what64) HIP_TRY(dev_malloc((void**)&p->ck_what64, n * sizeof(double2)));
     // on the plan's stream: ordered behind the iterations already queued, in front of the ones that follow
     HIP_TRY(hipMemcpyAsync(p->ck_what, p->What, n * sizeof(float2), hipMemcpyDeviceToDevice, p->stream));
     HIP_TRY(hipMemcpyAsync(p->ck_what64, p->What64, n * sizeof(double2), hipMemcpyDeviceToDevice, p->stream));
@@ -1373,7 +1404,7 @@ int oiva_plan_restore_w(oiva_plan* p) {
 
 static int fused_setup(oiva_plan* p) {
     const size_t words = 16 + (size_t)rsum_blocks(p->T) * p->K;
-    if (!p->fx_state) HIP_TRY(hipMalloc((void**)&p->fx_state, words * sizeof(unsigned)));
+    if (!p->fx_state) HIP_TRY(dev_malloc((void**)&p->fx_state, words * sizeof(unsigned)));
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemset(p->fx_state, 0, words * sizeof(unsigned)));
     return drop_graph(p);                       // captured graphs hold the other activation kernel
@@ -1802,7 +1833,7 @@ int oiva_plan_ogive_begin(oiva_plan* p, int update_mode, int model) {
         hipError_t e = hipSuccess;
         auto alloc = [&](size_t bytes) -> void* {
             void* ptr = nullptr;
-            if (e == hipSuccess) e = hipMalloc(&ptr, bytes);
+            if (e == hipSuccess) e = dev_malloc(&ptr, bytes);
             if (ptr) p->og_bufs.push_back(ptr);
             return ptr;
         };

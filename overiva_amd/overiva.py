@@ -19,11 +19,13 @@ Documented deviations from the reference:
 * the returned ``W`` is a fresh contiguous ``(n_freq, n_chan, n_src)`` array, not a view of ``W_hat``
   (``overiva.py:90,201-202``).
 """
+import atexit
 import os
 
 import numpy as np
 
 from . import sharded
+from ._lib import HipError
 from .plan import DeviceX, Plan
 
 _device = None
@@ -67,6 +69,22 @@ def release_cached_buffers():
     while _plan_cache:
         _plan_cache.pop(next(iter(_plan_cache))).close()
     _lib.check(_lib.load().oiva_pool_trim())
+
+
+def _release_at_exit():
+    """kept plans are destroyed while the HIP runtime is still there, not by ``Plan.__del__`` at interpreter finalisation"""
+    from . import _lib
+
+    if _lib._lib is None or not _plan_cache:      # (nothing kept: no GPU call at exit -- the process's memory goes with it anyway)
+        return
+    try:
+        while _plan_cache:
+            _plan_cache.pop(next(iter(_plan_cache))).close()
+    except Exception:
+        pass
+
+
+atexit.register(_release_at_exit)
 
 
 _last_info = {}
@@ -166,6 +184,23 @@ def overiva(
     if n_iter < 0:
         raise ValueError("n_iter must be >= 0")
 
+    args = (X, dtype, n_src, n_iter, proj_back, W0, model, init_eig, return_filters)
+    called_back = []
+    cb = None if callback is None else (lambda Y: (called_back.append(1), callback(Y))[1])
+    try:
+        return _solve(*args, cb)
+    except HipError as e:
+        # The plans kept between calls (up to _PLAN_CACHE_MAX, ~0.7 GB each at the headline shape) are memory the caller
+        # believes free: when the device runs out, they are destroyed and the call is made once more (the library itself
+        # already hands its pooled buffers back before an allocation fails, csrc/plan.hip::dev_malloc).
+        if "out of memory" not in str(e).lower() or not _plan_cache or called_back:
+            raise
+    release_cached_buffers()
+    return _solve(*args, cb)
+
+
+def _solve(X, dtype, n_src, n_iter, proj_back, W0, model, init_eig, return_filters, callback):
+    n_frames, n_freq, n_chan = X.shape
     precision = resolve_precision(dtype, n_chan, n_src=n_src)
     group = sharded.active_group()
     if group is not None and isinstance(X, DeviceX):
