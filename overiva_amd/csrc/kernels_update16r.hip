@@ -17,8 +17,13 @@
 // About 45 instructions per step and FOUR bins: a sixth of the instructions per bin.
 // C is kept by COLUMNS (lane c holds C[0..15][c]): y = w^H C and the rank-one update then need only broadcasts of w and
 // u / y_s (again row_newbcast), and u = C e_s -- the 16 registers of lane s -- reaches the rows through 1 KB of LDS.
-// The partial covariances of source s + 1 ([split][bin][source][M * M] float64, packed Hermitian) are moved into LDS by
-// DMA (global_load_lds, no registers) while source s is solved.
+//
+// THREE WAVES per four bins.  The elimination of V_s does not depend on the chain through the sources -- only its right-hand
+// side u does -- so it is split off: waves 1 and 2 (sources of even / odd number) add the frame splits' partial covariances
+// (loaded straight into registers, a source ahead), eliminate V_s with the multipliers A[i][k] / A[k][k] RECORDED, and hand
+// the lanes' 16 multipliers + reciprocal pivot to wave 0 through LDS (17 KB per source, two buffers, two flag words each
+// way); wave 0 inverts W_hat^H, then per source applies the recorded row operations to u (64 multiply-adds), forms y,
+// updates C and stores the new row of W_hat.  Same operations on the same numbers as one wave doing all of it in turn.
 #include "oiva_device.h"
 
 #include <cstdint>
@@ -32,7 +37,7 @@ constexpr int N = 16;
 constexpr int kBinsPerWaveR = 4;
 constexpr int kMaxSplitsR = 4;      // frame splits staged in LDS (more: the one-matrix-per-wave kernel)
 
-struct Z {
+struct alignas(16) Z {       // (16-byte alignment: one ds_read_b128 / ds_write_b128 with a 16-bit immediate offset per value in LDS)
     double re, im;
 };
 
@@ -87,13 +92,15 @@ __device__ __forceinline__ double rcp_nr(double a) {
     d = fma(fma(-a, d, 1.0), d, d);
     return d;
 }
+// 1 / sqrt(a), the same way (the IEEE division and square root are about sixty dependent instructions on the chain's critical path)
+__device__ __forceinline__ double rsq_nr(double a) {
+    double r = __builtin_amdgcn_rsq(a);
+    r = fma(0.5 * r, fma(-a * r, r, 1.0), r);
+    return fma(0.5 * r, fma(-a * r, r, 1.0), r);
+}
 __device__ __forceinline__ Z zmul(Z a, Z b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ Z zinv_fast(Z a) {
     const double d = rcp_nr(a.re * a.re + a.im * a.im);
-    return {a.re * d, -a.im * d};
-}
-__device__ __forceinline__ Z zinv(Z a) {
-    const double d = 1.0 / (a.re * a.re + a.im * a.im);
     return {a.re * d, -a.im * d};
 }
 // a -= m * r
@@ -109,59 +116,202 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename VT>
+
+constexpr int kFacPlanes = N + 1;       // 16 multipliers + the reciprocal pivot, per lane
+
+// (tools/build_variant.py ... -DOIVA_R16_TRACE: clock stamps of workgroup 0, read by tools/r6/det16_trace.py)
+#ifdef OIVA_R16_TRACE
+__device__ unsigned long long g_r16_trace[3 * 80];
+__device__ unsigned g_r16_hwid[2 * 3 * 1024];           // (HW_ID, XCC_ID) of every wave
+#define R16_STAMP(slot)                                                                                   \
+    do {                                                                                                  \
+        if (blockIdx.x == 0 && lane == 0) g_r16_trace[wave * 80 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define R16_STAMP(slot) \
+    do {                \
+    } while (0)
+#endif
+
 struct LdsR {
-    VT stage[kMaxSplitsR][kBinsPerWaveR][N * N];       // partial covariances of one source, as the covariance kernel stored them
-    double vsum[kBinsPerWaveR * N * N + 2];             // their sum over the splits / T (packed Hermitian blocks of 256; + 2: the neighbour read of the last diagonal)
-    Z sq[kBinsPerWaveR][N][N];                          // C-phase: the inverse's rows, filed under the column they pivoted
+    // (the small, busy arrays first: an LDS instruction's immediate offset reaches 64 KB)
     Z prow[kBinsPerWaveR][N];                           // C-phase: pivot row
     Z ppiv[kBinsPerWaveR];                              //          pivot element
     Z ucol[kBinsPerWaveR][N];                           // u = C e_s by row index
     Z ys[kBinsPerWaveR];                                // y_s
+    int ready[2], consumed[2];                          // sources handed over / taken, + 1, per buffer
+    Z fac[2][kFacPlanes][64];                           // [buffer = source parity][plane][lane]: the recorded elimination of V_s
+    Z sq[kBinsPerWaveR][N][N];                          // C-phase: the inverse's rows, filed under the column they pivoted
+    double vsum[2][kBinsPerWaveR * N * N + 2];          // per eliminating wave: sum of the splits / T (packed Hermitian blocks of 256; + 2: the neighbour read of the last diagonal)
 };
 
-template <typename VT>
-__global__ __launch_bounds__(64) void update_det16r_kernel(UpdateArgs a) {
-    __shared__ LdsR<VT> s;
-    const int lane = threadIdx.x, g = lane >> 4, i = lane & 15;
+// one wavefront against LDS: LDS operations of a wave complete in order
+__device__ __forceinline__ void lds_wait() { __builtin_amdgcn_s_waitcnt(0xc07f); }   // lgkmcnt(0)
+
+__device__ __forceinline__ void spin_until(const int* flag, int value) {
+    while (*const_cast<const volatile int*>(flag) < value) __builtin_amdgcn_s_sleep(1);
+}
+
+__global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
+    __shared__ LdsR s;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
     const int M = a.M, NA = M * M;
     const int fraw = blockIdx.x * kBinsPerWaveR + g;
-    const bool live = fraw < a.F;                          // (the last wave of a bin count that is no multiple of 4)
+    const bool live = fraw < a.F;                          // (the last workgroup of a bin count that is no multiple of 4)
     const int f = live ? fraw : a.F - 1;
     const Z zero = {0., 0.};
+#ifdef OIVA_R16_TRACE
+    if (lane == 0 && blockIdx.x < 1024) {
+        g_r16_hwid[(blockIdx.x * 3 + wave) * 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_r16_hwid[(blockIdx.x * 3 + wave) * 2 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
+    if (threadIdx.x < 2) {
+        s.ready[threadIdx.x] = 0;
+        s.consumed[threadIdx.x] = 0;
+    }
+    __syncthreads();
 
-    // ---- DMA of the partials of one source into s.stage: blocks of NA values per (split, bin), 16 bytes per lane and request
-    const VT* vbase = static_cast<const VT*>(a.Vpart);
-    const size_t vstride = (size_t)a.F * M * NA;
-    const int nsplit = a.nsplit;
-    const unsigned blk_bytes = (unsigned)NA * (unsigned)sizeof(VT);
-    const int npiece = (int)((blk_bytes + 1023u) / 1024u);                 // requests per block (<= 2)
-    auto stage_source = [&](int src) {
-        for (int sp = 0; sp < nsplit; ++sp) {
+    if (wave != 0) {
+        // =============== waves 1, 2: V_s of the sources b, b + 2, ... summed over the splits and eliminated ===============
+        const int b = wave - 1;
+        const double* vbase = static_cast<const double*>(a.Vpart);
+        const size_t vstride = (size_t)a.F * M * NA;
+        const int nsplit = a.nsplit;
+        const unsigned blk_bytes = (unsigned)NA * 8u;
+        constexpr int kPieces = kBinsPerWaveR * N * N / 2 / 64;        // 16-byte pieces per lane and split (8): piece lane + 64 j
+        // piece lane + 64 j of a split: bin j >> 1 of the workgroup, 1 KB (j & 1) of its block -- a uniform block address (scalar
+        // registers) + the lane's byte offset
+        unsigned loff[2];
 #pragma unroll
-            for (int gg = 0; gg < kBinsPerWaveR; ++gg) {
-                const int fr = blockIdx.x * kBinsPerWaveR + gg;
-                const int fg = fr < a.F ? fr : a.F - 1;
-                const char* blk = reinterpret_cast<const char*>(vbase + (size_t)sp * vstride + ((size_t)fg * M + src) * NA);
-                for (int pc = 0; pc < npiece; ++pc) {
-                    unsigned off = (unsigned)(pc * 64 + lane) * 16u;
-                    off = off + 16u <= blk_bytes ? off : 0u;               // lanes past the block re-read its start (their LDS words are not used)
-                    __builtin_amdgcn_global_load_lds((gvoid_t*)(blk + off), (lvoid_t*)(reinterpret_cast<char*>(&s.stage[sp][gg][0]) + pc * 1024), 16, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+            const unsigned off = (unsigned)(h * 64 + lane) * 16u;
+            loff[h] = off < blk_bytes ? off : 0u;          // lanes past the block re-read its start (their sums are not used); odd M: the last piece runs 8 bytes over (the next block, or the buffer's slack)
+        }
+        size_t bin_off[kBinsPerWaveR];                     // (uniform) first value of the bins' blocks inside a split
+#pragma unroll
+        for (int gg = 0; gg < kBinsPerWaveR; ++gg) {
+            const int fr = blockIdx.x * kBinsPerWaveR + gg;
+            bin_off[gg] = (size_t)(fr < a.F ? fr : a.F - 1) * M * NA;
+        }
+        // The partials travel in two batches of (at most) two splits, 64 registers: splits 0, 1 of the next source of this wave are
+        // requested before the elimination of the current one and added in the middle of it, where splits 2, 3 are requested; those
+        // are added when the elimination is over.  (All four at once: 128 registers in flight, 324 with the rest -- one wave per SIMD.)
+        double2 P[2][kPieces], acc[kPieces];
+        auto load_pair = [&](int src, int sp0) {
+            const size_t soff = (size_t)src * NA;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (sp0 + u < nsplit) {                     // (uniform)
+#pragma unroll
+                    for (int j = 0; j < kPieces; ++j)
+                        P[u][j] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(vbase + (size_t)(sp0 + u) * vstride + bin_off[j >> 1] + soff) + loff[j & 1]);
+                }
+        };
+        // acc (+)= the batch, in split order (first: acc = split 0)
+        auto add_pair = [&](int sp0) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (sp0 + u < nsplit) {
+#pragma unroll
+                    for (int j = 0; j < kPieces; ++j) {
+                        if (sp0 + u == 0) {
+                            acc[j] = P[u][j];
+                        } else {
+                            acc[j].x += P[u][j].x;
+                            acc[j].y += P[u][j].y;
+                        }
+                    }
+                }
+        };
+        // where row i of a packed Hermitian block lies: index of (re, im) of entry (i, c); the imaginary part changes sign below the diagonal
+        int voff[N];
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            const int lo = i < c ? i : c, hi = i < c ? c : i;
+            voff[c] = g * (N * N) + ((i == c || hi >= M) ? (i < M ? i : 0) : herm_pair_index(M, lo, hi));
+        }
+        const double invT = 1.0 / (double)a.T;
+        double* vs = &s.vsum[b][0];
+        if (b < M) {
+            load_pair(b, 0);
+            add_pair(0);
+            if (nsplit > 2) load_pair(b, 2);
+        }
+        for (int src = b; src < M; src += 2) {
+            // the sum over the splits, in order, times 1 / T, in the layout the partials arrived in
+            R16_STAMP(src * 4 + 0);
+            if (nsplit > 2) add_pair(2);
+            R16_STAMP(src * 4 + 1);
+            lds_wait();
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < kPieces; ++j) reinterpret_cast<double2*>(vs)[lane + 64 * j] = make_double2(acc[j].x * invT, acc[j].y * invT);
+            const bool more = src + 2 < M;
+            if (more) load_pair(src + 2, 0);               // in flight while this source is eliminated
+            lds_wait();
+            __builtin_amdgcn_wave_barrier();
+            // V_s, row i
+            Z V[N];
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                V[c] = {i == c ? 1. : 0., 0.};
+                if (c < M) {                                // (uniform)
+                    const double vr = vs[voff[c]], vi = vs[voff[c] + 1];
+                    if (i < M) {
+                        V[c].re = vr;
+                        V[c].im = i == c ? 0. : (i < c ? vi : -vi);
+                    }
                 }
             }
-        }
-    };
-    stage_source(0);
-
-    // ---- where row i of a packed Hermitian block lies: byte offset of (re, im) of entry (i, c), sign of the imaginary part
-    int voff[N];
+            dpp_fence();
+            // Gauss-Jordan without pivot search (Hermitian positive definite; identity outside M x M), columns <= k skipped; the
+            // pivot row by row_newbcast; the multiplier of step k stays in V[k] (0 on the pivot row itself)
+            double dmine = 1.;
+            auto step = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const double pk = bc<k>(V[k].re);          // A[k][k] (real: Schur complements stay Hermitian)
+                const double d = rcp_nr(pk);
+                const bool rowk = i == k;
+                dmine = rowk ? d : dmine;
+                V[k] = {rowk ? 0. : V[k].re * d, rowk ? 0. : V[k].im * d};
+                static_for<N - 1 - k>([&](auto jc) {
+                    constexpr int c = k + 1 + decltype(jc)::value;
+                    zsubmul_b<k>(V[c], V[k], V[c]);
+                });
+            };
+#define OIVA_R16_STEP(c) \
+    if (c < M) step(std::integral_constant<int, c>{});
+            OIVA_R16_STEP(0) OIVA_R16_STEP(1) OIVA_R16_STEP(2) OIVA_R16_STEP(3) OIVA_R16_STEP(4) OIVA_R16_STEP(5)
+            if (more) {                                     // (uniform) the next source's first two splits have arrived; its last two set out
+                add_pair(0);
+                if (nsplit > 2) load_pair(src + 2, 2);
+            }
+            OIVA_R16_STEP(6)
+            OIVA_R16_STEP(7) OIVA_R16_STEP(8) OIVA_R16_STEP(9) OIVA_R16_STEP(10) OIVA_R16_STEP(11) OIVA_R16_STEP(12)
+            OIVA_R16_STEP(13) OIVA_R16_STEP(14) OIVA_R16_STEP(15)
+#undef OIVA_R16_STEP
+            R16_STAMP(src * 4 + 2);
+            // hand-over: the buffer is free once wave 0 has taken source src - 2
+            if (src >= 2) spin_until(&s.consumed[b], src - 1);
 #pragma unroll
-    for (int c = 0; c < N; ++c) {
-        const int lo = i < c ? i : c, hi = i < c ? c : i;
-        voff[c] = (i == c || hi >= M) ? (i < M ? i : 0) : herm_pair_index(M, lo, hi);
+            for (int k = 0; k < N; ++k) s.fac[b][k][lane] = V[k];
+            s.fac[b][N][lane] = {dmine, 0.};
+            lds_wait();
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) *const_cast<volatile int*>(&s.ready[b]) = src + 1;
+            R16_STAMP(src * 4 + 3);
+        }
+        return;
     }
 
+    // =============== wave 0: C = (W_hat^H)^-1, then the chain through the sources ===============
+    // (the chain is the critical path of the workgroup: where this wave shares its SIMD with an eliminating wave it goes first)
+    __builtin_amdgcn_s_setprio(3);
     // ---- B = W_hat^H (identity outside M x M), rows scaled by 1 / wscale (overiva.py:163 / :167); lane (g, i): row i
+    R16_STAMP(64);
     Z A[N];
 #pragma unroll
     for (int c = 0; c < N; ++c) {
@@ -177,7 +327,6 @@ __global__ __launch_bounds__(64) void update_det16r_kernel(UpdateArgs a) {
 #pragma unroll
         for (int c = 0; c < N; ++c) A[c] = {A[c].re * sc, A[c].im * sc};
     }
-
     // ---- C = B^-1: in-place Gauss-Jordan with partial pivoting, rows never move.  Step c: the pivot row p (largest |A[i][c]|
     //      among the rows not used yet) goes through LDS with 1 in slot c; A[i][j] -= (A[i][c] / A[p][c]) row[j] for every j with
     //      A[i][c] cleared first, which leaves -multiplier in slot c (column p of the would-be right-hand side) and 1 on the
@@ -190,24 +339,45 @@ __global__ __launch_bounds__(64) void update_det16r_kernel(UpdateArgs a) {
         int mycol = i;
         auto step = [&](auto cc) {
             constexpr int c = decltype(cc)::value;
+            if (c == 8) R16_STAMP(66);
+            if (c == 9) R16_STAMP(72);
             const Z aic = A[c];
             const float mag = (float)(aic.re * aic.re + aic.im * aic.im);
             unsigned key = used ? 0u : ((__float_as_uint(mag) & ~31u) | 16u | (unsigned)(15 - i));
-            unsigned o;
-            o = dppu<0x121>(key); key = o > key ? o : key;     // row_ror:1, 2, 4, 8: the maximum over the 16 lanes of the row
-            o = dppu<0x122>(key); key = o > key ? o : key;
-            o = dppu<0x124>(key); key = o > key ? o : key;
-            o = dppu<0x128>(key); key = o > key ? o : key;
+            // the maximum over the 16 lanes of the row: row_ror:1, 2, 4, 8 as the DPP control of v_max_u32 itself (two wait states
+            // between a vector write and a DPP read of the same register)
+            asm volatile("s_nop 1\n\t"
+                         "v_max_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_max_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_max_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\t"
+                         "v_max_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+                         : "+v"(key));
             const int p = 15 - (int)(key & 15u);
             const bool mine = i == p;
+            if (c == 8) R16_STAMP(67);
             wave_lds_sync();
+            if (c == 8) R16_STAMP(68);
             if (mine) {
 #pragma unroll
                 for (int j = 0; j < N; ++j) s.prow[g][j] = j == c ? Z{1., 0.} : A[j];
                 s.ppiv[g] = aic;
             }
             wave_lds_sync();
+            if (c == 8) R16_STAMP(69);
+            // (every read of the pivot row requested before the first is waited for: hipcc's own schedule kept two in flight and paid
+            //  nine LDS round trips per step)
             const Z apc = s.ppiv[g];
+            Z row[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) row[j] = s.prow[g][j];
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == 8) {
+                lds_wait();
+                R16_STAMP(70);
+            }
             used = used || mine;
             mycol = mine ? c : mycol;
             piv.re = mine ? apc.re : piv.re;
@@ -217,7 +387,7 @@ __global__ __launch_bounds__(64) void update_det16r_kernel(UpdateArgs a) {
             fct.im = mine ? 0. : fct.im;
             A[c] = {mine ? 1. : 0., 0.};
 #pragma unroll
-            for (int j = 0; j < N; ++j) zsubmul(A[j], fct, s.prow[g][j]);
+            for (int j = 0; j < N; ++j) zsubmul(A[j], fct, row[j]);
         };
 #define OIVA_R16_STEP(c) \
     if (c < M) step(std::integral_constant<int, c>{});
@@ -227,7 +397,7 @@ __global__ __launch_bounds__(64) void update_det16r_kernel(UpdateArgs a) {
 #undef OIVA_R16_STEP
         wave_lds_sync();
         {
-            const Z ip = zinv(piv);
+            const Z ip = zinv_fast(piv);
 #pragma unroll
             for (int j = 0; j < N; ++j) s.sq[g][mycol][j] = zmul(A[j], ip);
         }
@@ -238,94 +408,51 @@ __global__ __launch_bounds__(64) void update_det16r_kernel(UpdateArgs a) {
         wave_lds_sync();
     }
 
-    // ---- A x = rhs for a Hermitian positive definite A (identity outside M x M), one row per lane: Gauss-Jordan without pivot
-    //      search on [A | rhs], columns <= k skipped; the pivot row by row_newbcast.  Returns x_i.
-    auto solve_hpd = [&](Z (&V)[N], Z rhs) -> Z {
-        double dmine = 1.;
-        auto step = [&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const double pk = bc<k>(V[k].re);              // A[k][k] (real: Schur complements stay Hermitian)
-            const double d = rcp_nr(pk);
-            const bool rowk = i == k;
-            dmine = rowk ? d : dmine;
-            const Z m = {rowk ? 0. : V[k].re * d, rowk ? 0. : V[k].im * d};      // the pivot row eliminates with factor 0
-            static_for<N - 1 - k>([&](auto jc) {
-                constexpr int c = k + 1 + decltype(jc)::value;
-                zsubmul_b<k>(V[c], m, V[c]);
-            });
-            zsubmul_b<k>(rhs, m, rhs);
-        };
-#define OIVA_R16_STEP(c) \
-    if (c < M) step(std::integral_constant<int, c>{});
-        OIVA_R16_STEP(0) OIVA_R16_STEP(1) OIVA_R16_STEP(2) OIVA_R16_STEP(3) OIVA_R16_STEP(4) OIVA_R16_STEP(5) OIVA_R16_STEP(6)
-        OIVA_R16_STEP(7) OIVA_R16_STEP(8) OIVA_R16_STEP(9) OIVA_R16_STEP(10) OIVA_R16_STEP(11) OIVA_R16_STEP(12)
-        OIVA_R16_STEP(13) OIVA_R16_STEP(14) OIVA_R16_STEP(15)
-#undef OIVA_R16_STEP
-        return {rhs.re * dmine, rhs.im * dmine};
-    };
 
-    const double invT = 1.0 / (double)a.T;
+    R16_STAMP(65);
     for (int src = 0; src < M; ++src) {
+        const int b = src & 1;
+        R16_STAMP(src * 4 + 0);
         // u = C e_src: the 16 registers of lane src, to the rows through LDS
         wave_lds_sync();
         if (i == src) {
 #pragma unroll
             for (int r = 0; r < N; ++r) s.ucol[g][r] = C[r];
         }
-        // the staged partials of this source have arrived (the only vector-memory traffic in flight besides stores).  Their sum
-        // over the splits, in order, times 1 / T -- in the layout they arrived in: lane l adds the 16-byte pieces l + 64 j of the
-        // four bins' blocks -- goes to s.vsum, and the DMA of the next source is requested at once.
-        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
         wave_lds_sync();
-        const Z ui = s.ucol[g][i];
-        {
-            constexpr int kPieces = kBinsPerWaveR * N * N / 2 / 64;        // 16-byte pieces per lane and split (8)
-            const double2* st = reinterpret_cast<const double2*>(&s.stage[0][0][0]);
-            double2 acc[kPieces];
+        Z rhs = s.ucol[g][i];
+        const Z ui = rhs;
+        // the recorded elimination of V_src
+        R16_STAMP(src * 4 + 1);
+        spin_until(&s.ready[b], src + 1);
+        R16_STAMP(src * 4 + 2);
+        Z F[N];
 #pragma unroll
-            for (int j = 0; j < kPieces; ++j) acc[j] = st[lane + 64 * j];
-#pragma unroll
-            for (int sp = 1; sp < kMaxSplitsR; ++sp)
-                if (sp < nsplit) {                          // (uniform)
-#pragma unroll
-                    for (int j = 0; j < kPieces; ++j) {
-                        const double2 v = st[sp * (kBinsPerWaveR * N * N / 2) + lane + 64 * j];
-                        acc[j].x += v.x;
-                        acc[j].y += v.y;
-                    }
-                }
-            double2* vs = reinterpret_cast<double2*>(&s.vsum[0]);
-#pragma unroll
-            for (int j = 0; j < kPieces; ++j) vs[lane + 64 * j] = make_double2(acc[j].x * invT, acc[j].y * invT);
-        }
-        wave_lds_sync();
-        if (src + 1 < M) stage_source(src + 1);
-        // V_s, row i: entry (i, c) of the packed Hermitian block, the imaginary part negated below the diagonal
-        Z V[N];
-#pragma unroll
-        for (int c = 0; c < N; ++c) {
-            V[c] = {i == c ? 1. : 0., 0.};
-            if (c < M) {                                    // (uniform)
-                const double vr = s.vsum[g * (N * N) + voff[c]], vi = s.vsum[g * (N * N) + voff[c] + 1];
-                if (i < M) {
-                    V[c].re = vr;
-                    V[c].im = i == c ? 0. : (i < c ? vi : -vi);
-                }
-            }
-        }
+        for (int k = 0; k < N; ++k) F[k] = s.fac[b][k][lane];
+        const double dmine = s.fac[b][N][lane].re;
+        lds_wait();
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) *const_cast<volatile int*>(&s.consumed[b]) = src + 1;
+        // w = V^-1 u (not yet normalised): the row operations on u, then the division by the pivots
         dpp_fence();
-        // w = V^-1 u (not yet normalised)
-        const Z wi = solve_hpd(V, ui);
+        static_for<N>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (k < M) zsubmul_b<k>(rhs, F[k], rhs);
+        });
+        const Z wi = {rhs.re * dmine, rhs.im * dmine};
         // y = w^H C: lane c forms column c, w_r by broadcast
-        Z y = zero;
+        // (four running sums: a dependent v_fmac_f64 issues every 8 cycles, an independent one every 4)
+        Z y = zero, y2 = zero;
         dpp_fence();
         static_for<N>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             fmacb<r>(y.re, wi.re, C[r].re);
-            fmacb<r>(y.re, wi.im, C[r].im);
+            fmacb<r>(y2.re, wi.im, C[r].im);
             fmacb<r>(y.im, wi.re, C[r].im);
-            fmacb_neg<r>(y.im, wi.im, C[r].re);
+            fmacb_neg<r>(y2.im, wi.im, C[r].re);
         });
+        y.re += y2.re;
+        y.im += y2.im;
         // y_src = w^H u = w^H V w =: d (overiva.py:185; real for the exact w): the normalisation takes its real part, the
         // Sherman-Morrison step divides by the COMPLEX value the rounded w gives (see update_det_kernel)
         wave_lds_sync();
@@ -333,7 +460,7 @@ __global__ __launch_bounds__(64) void update_det16r_kernel(UpdateArgs a) {
         wave_lds_sync();
         const Z ys = s.ys[g];
         const double d = ys.re;
-        const double sc = 1.0 / sqrt(d);
+        const double sc = rsq_nr(d);
         const Z gi = zmul(ui, zinv_fast(ys));
         const double sqd = d * sc;
         Z ye = y;
@@ -350,6 +477,7 @@ __global__ __launch_bounds__(64) void update_det16r_kernel(UpdateArgs a) {
         });
         // row src of W_hat^H = (w / sqrt(d))^H, i.e. W_hat[f][i][src] = w_i / sqrt(d)
         if (live && i < M) store_what<double>(a, ((size_t)f * M + i) * M + src, wi.re * sc, wi.im * sc);
+        R16_STAMP(src * 4 + 3);
     }
 }
 
@@ -364,8 +492,17 @@ bool update_det16r_applies(const UpdateArgs& a) {
 hipError_t launch_update_det16r(hipStream_t s, const UpdateArgs& a) {
     const dim3 grid((a.F + kBinsPerWaveR - 1) / kBinsPerWaveR);
     if (!a.vpart_f64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(update_det16r_kernel<double>, grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(update_det16r_kernel, grid, dim3(192), 0, s, a);
     return hipGetLastError();
 }
+
+#ifdef OIVA_R16_TRACE
+extern "C" int oiva_debug_r16_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_r16_trace), sizeof(g_r16_trace));
+}
+extern "C" int oiva_debug_r16_hwid(unsigned* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_r16_hwid), sizeof(g_r16_hwid));
+}
+#endif
 
 }  // namespace oiva

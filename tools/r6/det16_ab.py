@@ -6,17 +6,18 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, overiva_amd as oa
 T, F, M, K = [int(a) for a in sys.argv[1:5]] if len(sys.argv) > 4 else (4000, 2048, 16, 16)
-tag = os.environ.get("OIVA_DET16_ROWS", "1")
+tag = os.environ.get("OIVA_DET16_ROWS", "1") + os.environ.get("OIVA_HMFMA_INNER", "")
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 X = torch.view_as_complex(torch.randn((T, F, M, 2), generator=g, device="cuda"))
 p = oa.Plan(T, F, M, K, "laplace"); p.set_precision("mixed"); p.set_x_device(X.data_ptr(), X); p.covariance(); p.set_w(None); p.iterate(3); p.sync()
 W = p.get_w(np.complex128)
 os.makedirs("gpurun_out", exist_ok=True)
 np.save(f"gpurun_out/det16_w_{tag}_{F}x{T}x{M}.npy", W)
-other = f"gpurun_out/det16_w_{'0' if tag == '1' else '1'}_{F}x{T}x{M}.npy"
-if os.path.exists(other):
+import glob
+for other in sorted(glob.glob(f"gpurun_out/det16_w_*_{F}x{T}x{M}.npy")):
+    if other.endswith(f"det16_w_{tag}_{F}x{T}x{M}.npy"): continue
     Wo = np.load(other)
-    print(f"rows={tag}: W vs other form after 3 iterations: rel {np.linalg.norm(W - Wo) / np.linalg.norm(Wo):.3e}, finite {np.isfinite(W).all()}")
+    print(f"rows={tag}: W vs {os.path.basename(other)} after 3 iterations: rel {np.linalg.norm(W - Wo) / np.linalg.norm(Wo):.3e}, bit-equal {np.array_equal(W, Wo)}, finite {np.isfinite(W).all()}")
 for st in ("demix_power", "activation", "weighted_cov", "ip_update"):
     t = min(p.t_time_stage(st, 10) * 1e3 for _ in range(3))
     print(f"rows={tag} {F}x{T}x{M}: {st:14s} {t:8.1f} us", flush=True)
