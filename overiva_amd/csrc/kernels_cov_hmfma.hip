@@ -39,7 +39,6 @@ constexpr int kHmFrames = 4;                            // frames per stage of a
 constexpr int kHmSlot = 256;                            // bytes of two frames (one per accumulator set) x (<= 16) channels, 128 each
 constexpr int kHmX = kHmFrames * kHmSlot;               // 1 KB of X per stage per wave
 constexpr int kHmStage = kHmX + 512;                    // + 2 x 64 weights
-constexpr int kHmChunk = 32;                            // accumulators per LDS round of the epilogue: 4 groups x 2 sets x 4 (5 rounds for 17 groups)
 constexpr int kHmLdsStride = kBlock + 1;
 constexpr int kHmWeightStride = 16;                     // row stride of the weight table (launch_cov_weights)
 constexpr int kWtHalf = 4 * kHmFrames * kHmWeightStride * 4;      // bytes of the weight table between a frame and the one 16 later
@@ -109,7 +108,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
                                                               double* __restrict__ Vpart, int T, int F, int M, int Mv, int K, int tc) {
     constexpr int NG = M16 ? 16 : 17;
     constexpr int kRingBytes = kWaves * kHmStages * kHmStage;
-    constexpr int kScratchBytes = (int)sizeof(float) * kHmChunk * kHmLdsStride;
+    constexpr int kScratchBytes = 16 * 8 * kBlock;       // reduction scratch: 4 groups x 2 sets of 16-byte vectors per thread
     __shared__ float4 ring[(kRingBytes > kScratchBytes ? kRingBytes : kScratchBytes) / 16 + 1];
 
     const int tid = threadIdx.x;
@@ -427,50 +426,56 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     //      (M16, grp 15: lanes 0..7 the real part of (n, n + 8), lanes 8..15 the imaginary part of (n - 8, n)).
     //      A round = 4 groups; wave w adds the eight values of accumulator r = w of each, so that group, pair distance and
     //      re / im are compile-time and only (source row, channel) come from the lane.
-    float* lds = reinterpret_cast<float*>(ring);
+    // (round 6) A round = 4 groups; wave w adds GROUP w of the round -- all four accumulator registers (sources 4 q .. 4 q + 3) of
+    // it, so that the accumulators cross LDS as whole 16-byte vectors: 8 ds_write_b128 + 8 ds_read_b128 per lane and round where
+    // the round-4/5 form (wave w adds register w of every group) moved them one float at a time, 32 + 32 -- the same eight values
+    // in the same order into every sum, the same bits; the pass at four splits 633 -> 6xx us.  The group, and with it pair distance
+    // and re / im, is wave-uniform now (scalar registers), no longer compile-time.
+    f32x4* lds4 = reinterpret_cast<f32x4*>(ring);          // [group of the round][set][thread]
     const int NA = Mv * Mv;
-    double* vout = Vpart + (((size_t)blockIdx.y * F + f0) * K + 4 * q + wave) * NA;
-    const bool live = 4 * q + wave < K && n < M;
+    double* vout = Vpart + (((size_t)blockIdx.y * F + f0) * K + 4 * q) * NA;
 #pragma unroll
     for (int g0 = 0; g0 < NG; g0 += 4) {
         __syncthreads();
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    if (g0 + v < NG) lds[((v * 4 + r) * 2 + h) * kHmLdsStride + tid] = acc[h][g0 + v][r];
+            for (int h = 0; h < 2; ++h)
+                if (g0 + v < NG) lds4[(v * 2 + h) * kBlock + tid] = acc[h][g0 + v];
         __syncthreads();
+        const int grp = g0 + wave;                  // (wave-uniform)
+        if (grp >= NG) continue;
+        double s[4] = {0., 0., 0., 0.};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int grp = g0 + v;                 // compile-time
-            if (grp >= NG) continue;
-            const int c = (grp + 1) >> 1, im = (grp + 1) & 1;            // grp 2c-1: re, 2c: im   (grp 0: the diagonal)
-            double s = 0.;
+        for (int w = 0; w < kWaves; ++w)
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w)
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 t = lds4[(wave * 2 + h) * kBlock + w * 64 + lane];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) s += (double)lds[((v * 4 + wave) * 2 + h) * kHmLdsStride + w * 64 + lane];
-            if (!live) continue;
-            int pos;
-            if (grp == 0) {
-                if (n >= Mv) continue;
-                pos = n;
-            } else if (M16 && grp == 15) {
-                const int i8 = n & 7, j8 = i8 + 8;
-                if (j8 >= Mv) continue;
-                pos = herm_pair_index(Mv, i8, j8) + (n >> 3);
-            } else {
-                if (c > MH || (c == MH && n >= MH)) continue;             // (c = M/2: the upper half of the lanes repeats the lower)
-                const int mm = n + c >= M ? n + c - M : n + c;
-                const int i = n < mm ? n : mm, j = n < mm ? mm : n;
-                if (j >= Mv) continue;
-                pos = herm_pair_index(Mv, i, j) + im;
-                if (im && mm < n) s = -s;                                 // Im(x_i conj x_j) = -Im(x_j conj x_i)
+                for (int r = 0; r < 4; ++r) s[r] += (double)t[r];
             }
-            vout[pos] = s;
+        if (n >= M) continue;
+        const int c = (grp + 1) >> 1, im = (grp + 1) & 1;            // grp 2c-1: re, 2c: im   (grp 0: the diagonal)
+        int pos;
+        bool neg = false;
+        if (grp == 0) {
+            if (n >= Mv) continue;
+            pos = n;
+        } else if (M16 && grp == 15) {
+            const int i8 = n & 7, j8 = i8 + 8;
+            if (j8 >= Mv) continue;
+            pos = herm_pair_index(Mv, i8, j8) + (n >> 3);
+        } else {
+            if (c > MH || (c == MH && n >= MH)) continue;             // (c = M/2: the upper half of the lanes repeats the lower)
+            const int mm = n + c >= M ? n + c - M : n + c;
+            const int i = n < mm ? n : mm, j = n < mm ? mm : n;
+            if (j >= Mv) continue;
+            pos = herm_pair_index(Mv, i, j) + im;
+            neg = im && mm < n;                                       // Im(x_i conj x_j) = -Im(x_j conj x_i)
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < K) vout[(size_t)r * NA + pos] = neg ? -s[r] : s[r];
     }
 }
 

@@ -80,6 +80,13 @@ __device__ __forceinline__ void dpp_fence() {
     asm volatile("s_nop 1");
     __builtin_amdgcn_sched_barrier(0);
 }
+// value of lane K of the row (v_mov_b64_dpp behind its two wait states; the builtin costs a register copy more)
+template <int K>
+__device__ __forceinline__ double bcm(double x) {
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(K));
+    return r;
+}
 template <int CTRL>
 __device__ __forceinline__ unsigned dppu(unsigned x) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xf, 0xf, false);
@@ -272,11 +279,12 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
             double dmine = 1.;
             auto step = [&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                const double pk = bc<k>(V[k].re);          // A[k][k] (real: Schur complements stay Hermitian)
+                const double pk = bcm<k>(V[k].re);         // A[k][k] (real: Schur complements stay Hermitian)
                 const double d = rcp_nr(pk);
                 const bool rowk = i == k;
                 dmine = rowk ? d : dmine;
-                V[k] = {rowk ? 0. : V[k].re * d, rowk ? 0. : V[k].im * d};
+                const double dm = rowk ? 0. : d;           // the pivot row's own multiplier is 0
+                V[k] = {V[k].re * dm, V[k].im * dm};
                 static_for<N - 1 - k>([&](auto jc) {
                     constexpr int c = k + 1 + decltype(jc)::value;
                     zsubmul_b<k>(V[c], V[k], V[c]);

@@ -13,6 +13,8 @@ p = oa.Plan(T, F, M, K, "laplace"); p.set_precision("mixed"); p.set_x_device(X.d
 W = p.get_w(np.complex128)
 os.makedirs("gpurun_out", exist_ok=True)
 np.save(f"gpurun_out/det16_w_{tag}_{F}x{T}x{M}.npy", W)
+import hashlib
+print(f"rows={tag}: sha256(W after 3 iterations)[:16] = {hashlib.sha256(W.tobytes()).hexdigest()[:16]}")
 import glob
 for other in sorted(glob.glob(f"gpurun_out/det16_w_*_{F}x{T}x{M}.npy")):
     if other.endswith(f"det16_w_{tag}_{F}x{T}x{M}.npy"): continue
