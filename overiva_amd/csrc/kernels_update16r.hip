@@ -140,23 +140,31 @@ __device__ unsigned g_r16_hwid[2 * 3 * 1024];           // (HW_ID, XCC_ID) of ev
     } while (0)
 #endif
 
+constexpr int kFacBufs = 3;
 struct LdsR {
     // (the small, busy arrays first: an LDS instruction's immediate offset reaches 64 KB)
     Z prow[kBinsPerWaveR][N];                           // C-phase: pivot row
     Z ppiv[kBinsPerWaveR];                              //          pivot element
     Z ucol[kBinsPerWaveR][N];                           // u = C e_s by row index
     Z ys[kBinsPerWaveR];                                // y_s
-    int ready[2], consumed[2];                          // sources handed over / taken, + 1, per buffer
-    Z fac[2][kFacPlanes][64];                           // [buffer = source parity][plane][lane]: the recorded elimination of V_s
-    Z sq[kBinsPerWaveR][N][N];                          // C-phase: the inverse's rows, filed under the column they pivoted
+    int ready[kFacBufs], consumed[kFacBufs];            // sources handed over / taken, + 1, per buffer
+    int claim;                                          // next source nobody eliminates yet
+    int sq_done;                                        // wave 0 has C in registers: the last buffer is free
+    // [buffer = source mod 3][plane][lane]: the recorded elimination of V_s.  Three buffers: the eliminating waves run up to three
+    // sources ahead of the chain, which starts late (behind the inversion of W_hat^H).  The LAST one doubles as `sq` of that
+    // inversion -- the inverse's rows, filed under the column they pivoted, [bin][16][16] --: source 2 waits for sq_done.
+    Z fac[kFacBufs][kFacPlanes][64];
     double vsum[2][kBinsPerWaveR * N * N + 2];          // per eliminating wave: sum of the splits / T (packed Hermitian blocks of 256; + 2: the neighbour read of the last diagonal)
 };
+static_assert(sizeof(Z) * kBinsPerWaveR * N * N <= sizeof(Z) * kFacPlanes * 64, "sq fits a buffer");
 
 // one wavefront against LDS: LDS operations of a wave complete in order
 __device__ __forceinline__ void lds_wait() { __builtin_amdgcn_s_waitcnt(0xc07f); }   // lgkmcnt(0)
 
 __device__ __forceinline__ void spin_until(const int* flag, int value) {
+#ifndef OIVA_R16_NOSYNC          // (variant builds: each role alone, no hand-shake -- timing only, wrong results)
     while (*const_cast<const volatile int*>(flag) < value) __builtin_amdgcn_s_sleep(1);
+#endif
 }
 
 __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
@@ -174,12 +182,17 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
         g_r16_hwid[(blockIdx.x * 3 + wave) * 2 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 #endif
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < kFacBufs) {
         s.ready[threadIdx.x] = 0;
         s.consumed[threadIdx.x] = 0;
+        s.claim = 0;
+        s.sq_done = 0;
     }
     __syncthreads();
 
+#ifdef OIVA_R16_ONLY_A
+    if (wave != 0) return;
+#endif
     if (wave != 0) {
         // =============== waves 1, 2: V_s of the sources b, b + 2, ... summed over the splits and eliminated ===============
         const int b = wave - 1;
@@ -188,32 +201,30 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
         const int nsplit = a.nsplit;
         const unsigned blk_bytes = (unsigned)NA * 8u;
         constexpr int kPieces = kBinsPerWaveR * N * N / 2 / 64;        // 16-byte pieces per lane and split (8): piece lane + 64 j
-        // piece lane + 64 j of a split: bin j >> 1 of the workgroup, 1 KB (j & 1) of its block -- a uniform block address (scalar
-        // registers) + the lane's byte offset
-        unsigned loff[2];
+        // piece lane + 64 j of a split: bin j >> 1 of the workgroup, 1 KB (j & 1) of its block -- as the lane's byte offset from the
+        // block of the workgroup's first bin (bins past F: the last bin's block again), so that a split of a source has ONE uniform
+        // base address and a load is one instruction (scalar base + 32-bit lane offset)
+        const int f_first = blockIdx.x * kBinsPerWaveR;
+        unsigned poff[kPieces];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const unsigned off = (unsigned)(h * 64 + lane) * 16u;
-            loff[h] = off < blk_bytes ? off : 0u;          // lanes past the block re-read its start (their sums are not used); odd M: the last piece runs 8 bytes over (the next block, or the buffer's slack)
+        for (int j = 0; j < kPieces; ++j) {
+            const int fr = f_first + (j >> 1);
+            const unsigned off = (unsigned)((j & 1) * 64 + lane) * 16u;
+            // lanes past the block re-read its start (their sums are not used); odd M: the last piece runs 8 bytes over (the next block, or the buffer's slack)
+            poff[j] = (unsigned)((fr < a.F ? fr : a.F - 1) - f_first) * (unsigned)(M * NA * 8) + (off < blk_bytes ? off : 0u);
         }
-        size_t bin_off[kBinsPerWaveR];                     // (uniform) first value of the bins' blocks inside a split
-#pragma unroll
-        for (int gg = 0; gg < kBinsPerWaveR; ++gg) {
-            const int fr = blockIdx.x * kBinsPerWaveR + gg;
-            bin_off[gg] = (size_t)(fr < a.F ? fr : a.F - 1) * M * NA;
-        }
+        const char* wg_base = reinterpret_cast<const char*>(vbase + (size_t)f_first * M * NA);
         // The partials travel in two batches of (at most) two splits, 64 registers: splits 0, 1 of the next source of this wave are
         // requested before the elimination of the current one and added in the middle of it, where splits 2, 3 are requested; those
         // are added when the elimination is over.  (All four at once: 128 registers in flight, 324 with the rest -- one wave per SIMD.)
         double2 P[2][kPieces], acc[kPieces];
         auto load_pair = [&](int src, int sp0) {
-            const size_t soff = (size_t)src * NA;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (sp0 + u < nsplit) {                     // (uniform)
+                    const char* sbase = wg_base + ((size_t)(sp0 + u) * vstride + (size_t)src * NA) * 8;
 #pragma unroll
-                    for (int j = 0; j < kPieces; ++j)
-                        P[u][j] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(vbase + (size_t)(sp0 + u) * vstride + bin_off[j >> 1] + soff) + loff[j & 1]);
+                    for (int j = 0; j < kPieces; ++j) P[u][j] = *reinterpret_cast<const double2*>(sbase + poff[j]);
                 }
         };
         // acc (+)= the batch, in split order (first: acc = split 0)
@@ -242,12 +253,23 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
         }
         const double invT = 1.0 / (double)a.T;
         double* vs = &s.vsum[b][0];
-        if (b < M) {
-            load_pair(b, 0);
+        // The sources are not dealt out in advance: a wave takes the next one nobody has (a counter in LDS) when it starts on its
+        // current one -- the hardware places the six waves of two workgroups on a CU's four SIMDs as {A}, {A, B}, {B, B}, {B}, and a
+        // wave alone on its SIMD eliminates a source in half the time of one that shares it (2.5 against 5 us).  Source n goes
+        // through buffer n & 1 whoever eliminated it; wave 0 takes them in order.
+        auto claim = [&]() {
+            int nx = 0;
+            if (lane == 0) nx = atomicAdd(&s.claim, 1);
+            return __builtin_amdgcn_readfirstlane(nx);
+        };
+        int src = claim();
+        if (src < M) {
+            load_pair(src, 0);
             add_pair(0);
-            if (nsplit > 2) load_pair(b, 2);
+            if (nsplit > 2) load_pair(src, 2);
         }
-        for (int src = b; src < M; src += 2) {
+        while (src < M) {
+            const int fb = src % kFacBufs;
             // the sum over the splits, in order, times 1 / T, in the layout the partials arrived in
             R16_STAMP(src * 4 + 0);
             if (nsplit > 2) add_pair(2);
@@ -256,20 +278,28 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < kPieces; ++j) reinterpret_cast<double2*>(vs)[lane + 64 * j] = make_double2(acc[j].x * invT, acc[j].y * invT);
-            const bool more = src + 2 < M;
-            if (more) load_pair(src + 2, 0);               // in flight while this source is eliminated
+            const int nxt = claim();
+            const bool more = nxt < M;
+            if (more) load_pair(nxt, 0);                   // in flight while this source is eliminated
             lds_wait();
             __builtin_amdgcn_wave_barrier();
             // V_s, row i
+            // (the imaginary part of the diagonal entry is whatever lies behind it in the block: no step reads it -- the pivot is
+            //  V[k].re, and the pivot row's own multiplier is multiplied by 0)
             Z V[N];
+            if (M == N) {                                   // (uniform)
 #pragma unroll
-            for (int c = 0; c < N; ++c) {
-                V[c] = {i == c ? 1. : 0., 0.};
-                if (c < M) {                                // (uniform)
+                for (int c = 0; c < N; ++c) {
                     const double vr = vs[voff[c]], vi = vs[voff[c] + 1];
-                    if (i < M) {
-                        V[c].re = vr;
-                        V[c].im = i == c ? 0. : (i < c ? vi : -vi);
+                    V[c] = {vr, i < c ? vi : -vi};
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < N; ++c) {
+                    V[c] = {i == c ? 1. : 0., 0.};
+                    if (c < M) {                            // (uniform)
+                        const double vr = vs[voff[c]], vi = vs[voff[c] + 1];
+                        if (i < M) V[c] = {vr, i < c ? vi : -vi};
                     }
                 }
             }
@@ -295,26 +325,31 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
             OIVA_R16_STEP(0) OIVA_R16_STEP(1) OIVA_R16_STEP(2) OIVA_R16_STEP(3) OIVA_R16_STEP(4) OIVA_R16_STEP(5)
             if (more) {                                     // (uniform) the next source's first two splits have arrived; its last two set out
                 add_pair(0);
-                if (nsplit > 2) load_pair(src + 2, 2);
+                if (nsplit > 2) load_pair(nxt, 2);
             }
             OIVA_R16_STEP(6)
             OIVA_R16_STEP(7) OIVA_R16_STEP(8) OIVA_R16_STEP(9) OIVA_R16_STEP(10) OIVA_R16_STEP(11) OIVA_R16_STEP(12)
             OIVA_R16_STEP(13) OIVA_R16_STEP(14) OIVA_R16_STEP(15)
 #undef OIVA_R16_STEP
             R16_STAMP(src * 4 + 2);
-            // hand-over: the buffer is free once wave 0 has taken source src - 2
-            if (src >= 2) spin_until(&s.consumed[b], src - 1);
+            // hand-over: the buffer is free once wave 0 has taken source src - 3 (and, the last one, finished the inversion)
+            if (src >= kFacBufs) spin_until(&s.consumed[fb], src - kFacBufs + 1);
+            if (src == kFacBufs - 1) spin_until(&s.sq_done, 1);
 #pragma unroll
-            for (int k = 0; k < N; ++k) s.fac[b][k][lane] = V[k];
-            s.fac[b][N][lane] = {dmine, 0.};
+            for (int k = 0; k < N; ++k) s.fac[fb][k][lane] = V[k];
+            s.fac[fb][N][lane] = {dmine, 0.};
             lds_wait();
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) *const_cast<volatile int*>(&s.ready[b]) = src + 1;
+            if (lane == 0) *const_cast<volatile int*>(&s.ready[fb]) = src + 1;
             R16_STAMP(src * 4 + 3);
+            src = nxt;
         }
         return;
     }
 
+#ifdef OIVA_R16_ONLY_B
+    return;
+#endif
     // =============== wave 0: C = (W_hat^H)^-1, then the chain through the sources ===============
     // (the chain is the critical path of the workgroup: where this wave shares its SIMD with an eliminating wave it goes first)
     __builtin_amdgcn_s_setprio(3);
@@ -404,22 +439,24 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
         OIVA_R16_STEP(13) OIVA_R16_STEP(14) OIVA_R16_STEP(15)
 #undef OIVA_R16_STEP
         wave_lds_sync();
+        Z* sq = &s.fac[kFacBufs - 1][0][0];                 // (the last hand-over buffer, not yet in use)
         {
             const Z ip = zinv_fast(piv);
 #pragma unroll
-            for (int j = 0; j < N; ++j) s.sq[g][mycol][j] = zmul(A[j], ip);
+            for (int j = 0; j < N; ++j) sq[(g * N + mycol) * N + j] = zmul(A[j], ip);
         }
         wave_lds_sync();
         // lane j takes column j of the inverse: C[r][j] = sq[r][q_j]
 #pragma unroll
-        for (int r = 0; r < N; ++r) C[r] = s.sq[g][r][mycol];
+        for (int r = 0; r < N; ++r) C[r] = sq[(g * N + r) * N + mycol];
         wave_lds_sync();
+        if (lane == 0) *const_cast<volatile int*>(&s.sq_done) = 1;
     }
 
 
     R16_STAMP(65);
     for (int src = 0; src < M; ++src) {
-        const int b = src & 1;
+        const int b = src % kFacBufs;
         R16_STAMP(src * 4 + 0);
         // u = C e_src: the 16 registers of lane src, to the rows through LDS
         wave_lds_sync();

@@ -22,8 +22,12 @@ print(f"wave 0: start 0.00, C-phase done {us(t[0, 65]):.2f} us")
 print("C-phase step 8: start, argmax done, lds quiet, row written, row read, (step 9 start):", [round(us(v), 3) for v in (t[0, 66], t[0, 67], t[0, 68], t[0, 69], t[0, 70], t[0, 72])])
 for s_ in range(16):
     a = t[0, 4 * s_: 4 * s_ + 4]
-    b = t[1 + (s_ & 1), 4 * s_: 4 * s_ + 4]
-    print(f"src {s_:2d}: A top {us(a[0]):6.2f} wait-from {us(a[1]):6.2f} got {us(a[2]):6.2f} end {us(a[3]):6.2f} | B{s_ & 1} top {us(b[0]):6.2f} partials {us(b[1]):6.2f} solved {us(b[2]):6.2f} handed {us(b[3]):6.2f}")
+    print(f"src {s_:2d}: A top {us(a[0]):6.2f} wait-from {us(a[1]):6.2f} got {us(a[2]):6.2f} end {us(a[3]):6.2f}")
+for w in (1, 2):
+    rows = [(us(t[w, 4 * s_]), s_) for s_ in range(16) if t[w, 4 * s_] > 0 and abs(us(t[w, 4 * s_])) < 1e4]
+    for _, s_ in sorted(rows):
+        b = t[w, 4 * s_: 4 * s_ + 4]
+        print(f"wave {w} src {s_:2d}: top {us(b[0]):6.2f} partials {us(b[1]):6.2f} solved {us(b[2]):6.2f} handed {us(b[3]):6.2f}")
 
 hw = np.zeros(2 * 3 * 1024, np.uint32)
 lib.oiva_debug_r16_hwid.argtypes = [C.c_void_p]
