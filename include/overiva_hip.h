@@ -139,12 +139,14 @@ int oiva_plan_update(oiva_plan *p, const void *parts_dev, int nparts);
  */
 int oiva_plan_demix(oiva_plan *p, void *Y_host, long long row_pitch_bytes, int proj_back);
 /* Device buffers of >= 16 MB that a destroyed plan owned (its copy of X, Y, staging) stay in a process-wide pool for the next
- * plan of the same shape -- at most $OIVA_POOL_MB (default 2048; 0: nothing is kept).  This releases them to the driver. */
+ * plan of the same shape -- at most $OIVA_POOL_MB (default 2048; 0: nothing is kept).  This releases them to the driver; the
+ * library does so itself, and retries, before a device allocation of its own fails for want of memory. */
 int oiva_pool_trim(void);
 /* Bytes of output per slab of the hand-over above (0: the default, 8 MB).  Test hook. */
 int oiva_plan_set_io_slab(oiva_plan *p, long long bytes);
 /* Fault the pages of [ptr, ptr + bytes) in for writing, contents unchanged, using the library's copy threads.  Blocking;
- * callable from any thread (overiva() runs it beside the upload of X and the iterations on the array it will return). */
+ * callable from any thread (overiva() runs it on the array it will return while the queued iterations run on the GPU; beside the
+ * upload of X it slowed the upload by as much as it saved: dropped, round 5). */
 int oiva_host_prefault(void *ptr, long long bytes);
 /* Same, but Y stays on the device: *Y_dev is the plan's own (T, F, K) complex64 buffer, valid until the next demix of
  * this plan or its destruction.  Hand it to oiva_plan_set_x_dev of another plan to chain two solves without a host

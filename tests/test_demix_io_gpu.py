@@ -152,3 +152,31 @@ def test_graph_cache_eviction_pool_trim_and_replanning_keep_the_results(oa):
 
     for a, b in zip(run(False), run(True)):
         assert np.array_equal(a, b)
+
+
+def test_a_kept_plan_returns_the_iterated_w_in_fast_determined(oa):
+    """with `fast` (float32 per-bin algebra: the complex128 copy of W_hat is not maintained) and n_src == n_chan
+    (no J stage that would clear the flag), the second call of a shape replays the CACHED graph -- nothing is captured, so the
+    host flag "the complex128 copy is current" stayed true from the upload of W0 and get_w returned W0 = identity.  Two calls on
+    different data, each against a fresh plan."""
+    ov = sys.modules["overiva_amd.overiva"]
+    T, F, M = 1100, 1000, 8                            # 8.8 M elements: graphs and the plan cache apply
+    X1, X2 = orc.synth_iid(T, F, M, seed=11), orc.synth_mixture(T, F, M, M, seed=12)
+    oa.release_cached_buffers()
+    oa.set_precision("fast")
+    try:
+        kept = [oa.overiva(X, n_iter=3, proj_back=False, return_filters=True) for X in (X1, X2, X1)]
+        assert len(ov._plan_cache) >= 1
+        oa.release_cached_buffers()
+        keep, ov._PLAN_CACHE_MAX = ov._PLAN_CACHE_MAX, 0
+        try:
+            fresh = [oa.overiva(X, n_iter=3, proj_back=False, return_filters=True) for X in (X1, X2, X1)]
+        finally:
+            ov._PLAN_CACHE_MAX = keep
+    finally:
+        oa.set_precision("auto")
+        oa.release_cached_buffers()
+    eye = np.broadcast_to(np.eye(M, dtype=np.complex64), (F, M, M))
+    for (Yk, Wk), (Yf, Wf) in zip(kept, fresh):
+        assert np.array_equal(Yk, Yf) and np.array_equal(Wk, Wf)
+        assert not np.allclose(Wk, eye)                # (what the stale flag returned)

@@ -251,7 +251,8 @@ def test_ip_update(oa, golden, model, fp64, rows):
 @pytest.mark.parametrize("cond", [1e8, 1e10, 1e12])
 @pytest.mark.parametrize("M", [3, 4, 6, 8, 12, 16])
 def test_determined_update_on_ill_conditioned_covariances(oa, M, cond):
-    """ADVICE r4: the float64 update of the determined case (update_det_kernel up to 8 channels, update_det16_kernel above;
+    """the float64 update of the determined case (update_det_kernel up to 8 channels; above: update_det16r_kernel --
+    one matrix row per lane, three waves per four bins, round 6 --, with $OIVA_DET16_ROWS=0 update_det16_kernel;
     overiva.py:181-186) on covariances of condition number 1e8 .. 1e12 and a W_hat that is not adapted to them, against the
     oracle's chain (a pivoted solve with W_hat^H V_s per source) from the covariances the device itself formed: within 4 of
     the reference's OWN sensitivities to a change of V in its last bits.  (Round 4's form was up to 1e3 sensitivities off:
@@ -553,6 +554,9 @@ def test_odd_shapes_against_oracle(oa, shape, model):
     assert eW < bound and eY < 2 * bound
 
 
+_RANDOM_SKIPPED = []
+
+
 def _random_shapes(n=60, seed=123):
     rng = np.random.default_rng(seed)
     out = []
@@ -593,8 +597,13 @@ def test_random_shapes_against_oracle(oa, case):
             if floor is None:
                 floor = _c64_floor(lambda: orc.overiva_faithful(X, n_src=K, n_iter=3, proj_back=True, model=model, return_filters=True)[1], Wr)
             if not floor < 1e-2:
+                _RANDOM_SKIPPED.append(case)
+                assert len(_RANDOM_SKIPPED) <= 6, f"too many of the 60 random shapes skipped as chaotic: {_RANDOM_SKIPPED}"
                 pytest.skip(f"the reference's complex64 arithmetic is chaotic here (floor {floor:.1e}); ours {eW:.1e} ({dt.__name__})")
-            bound = max(TOL, 1.5 * floor)
+            #  the reference's complex64 floor loosens the bound of the complex64 leg only: complex128 input runs the
+            # float64 arithmetic (`precise`), which owes the 1e-5 whatever the complex64 arithmetic does on this input
+            if dt == np.complex64:
+                bound = max(TOL, 1.5 * floor)
         print(f"\n[parity] random {case[1:]} {dt.__name__}: W err {eW:.2e} Y err {eY:.2e} (bound {bound:.1e})")
         assert eW < bound and eY < 2 * bound, ((T, F, M, K), model, dt.__name__, eW, eY, floor)
 
@@ -798,22 +807,40 @@ def headline_iid():
     return X, ref
 
 
+def _one_launch_env(oa, monkeypatch, shape, on):
+    """$OIVA_COV_UPDATE for the plans overiva() creates from here on (read at plan creation: plans kept from earlier calls are
+    dropped); on: checks that a plan of this shape really runs covariance and update as ONE launch (cov_update_kernel)"""
+    oa.release_cached_buffers()
+    if not on:
+        monkeypatch.delenv("OIVA_COV_UPDATE", raising=False)
+        return
+    monkeypatch.setenv("OIVA_COV_UPDATE", "1")
+    T, F, M, K = shape
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_precision("mixed")
+        assert p.set_fuse_cov_update(True), "the one-launch form does not apply to this shape"
+
+
 @pytest.mark.parametrize("model", ["laplace", "gauss"])
-@pytest.mark.parametrize("mode", ["precise", "mixed", "fast"])
-def test_headline_size_against_oracle(oa, headline_iid, mode, model):
+@pytest.mark.parametrize("mode,one_launch", [("precise", False), ("mixed", False), ("fast", False), ("mixed", True), ("fast", True)])
+def test_headline_size_against_oracle(oa, headline_iid, mode, one_launch, model, monkeypatch):
     """2048 x 4000 x 8 / 2 (BASELINE.json configs[2]) end to end against the oracle's reference-faithful form
-    (the reference's own arithmetic: complex64 data, float64 activations) for a few iterations, both source models."""
+    (the reference's own arithmetic: complex64 data, float64 activations) for a few iterations, both source models.
+    one_launch: covariance + IP1 + J of a bin batch in ONE kernel (cov_update_kernel, the north star's fusion at this shape, opt-in
+    because it measures no faster) against the oracle directly, not only against the two launches' bits."""
     X, ref = headline_iid
     K = 2
+    _one_launch_env(oa, monkeypatch, (X.shape[0], X.shape[1], X.shape[2], K), one_launch)
     oa.set_precision(mode)
     try:
         Y, W = oa.overiva(X, n_src=K, n_iter=3, proj_back=False, model=model, return_filters=True)
     finally:
         oa.set_precision("auto")
+        oa.release_cached_buffers()
     Yr, Wr = ref[model]
     eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
-    _log(test="headline", fixture="T4000F2048M8K2 iid", model=model, n_iter=3, input="c64", mode=mode, W_vs_ref_c64=eW,
-         Y_vs_ref_c64=eY)
+    _log(test="headline" + ("-one-launch" if one_launch else ""), fixture="T4000F2048M8K2 iid", model=model, n_iter=3, input="c64", mode=mode,
+         W_vs_ref_c64=eW, Y_vs_ref_c64=eY)
     print(f"\n[parity] headline shape iid {model} 3 its {mode} vs reference-faithful c64: W err {eW:.2e}  Y err {eY:.2e}")
     assert eW < TOL and eY < TOL
 
@@ -851,8 +878,9 @@ def test_shard_size_mixture_20_iterations(oa, model):
 def test_cfg5_shape_full_frame_axis(oa, mode):
     """BASELINE.json configs[4] shape at full T with few bins: 8 bins x 4000 frames x 16 mics / 16 src, in every arithmetic
     -- `mixed` is what bench.py times and overiva() runs on it: cov_hmfma_kernel<true> (all 16 sources on the fp32 matrix
-    cores, Hermitian products by DPP rotation, float32 chains over the frame splits, float64 partials), the matrix-core
-    power pass of > 4 sources and update_det16_kernel<double> (maintained inverse, one wavefront per bin);
+    cores, Hermitian products from LDS partners, float32 chains over the frame splits, float64 partials), the matrix-core
+    power pass of > 4 sources (8 bins: power_mfma_kernel; whole 64-bin batches: power_lds_kernel) and update_det16r_kernel
+    (w = V_s^-1 u by one elimination per source with recorded multipliers, C = (W_hat^H)^-1 kept by rank-one steps);
     `precise`: cov_hmfma64_kernel (the same GEMM on the fp64 matrix cores); `fast`: float32 per-bin algebra"""
     T, F, M, K = 4000, 8, 16, 16
     X = orc.synth_iid(T, F, M, seed=5)
@@ -909,7 +937,7 @@ def test_headline_size_properties(oa):
 def test_cfg5_full_size_properties(oa, mode):
     """2048 bins x 4000 frames x 16 mics / 16 src (BASELINE.json configs[4]) at FULL size, in the geometry and the arithmetic
     bench.py times -- `mixed`: cov_hmfma_kernel<true> (the sources on the fp32 matrix cores, 4 frame splits, float64 partials),
-    power_mfma_kernel, update_det16_kernel<double> (maintained inverse, one wavefront per bin over 2048 bins); `precise`:
+    power_lds_kernel, update_det16r_kernel (one matrix row per lane, three waves per four bins: 512 workgroups); `precise`:
     cov_hmfma64_kernel + the same update; `fast`: cov_hmfma_kernel + update_wave16_kernel<float> -- invariants that need no
     oracle, the covariances of three bins against the oracle, and the per-bin update of those bins (overiva.py:181-190, all
     16 sources) against orc.ip_update_bin from the device's own covariances"""
@@ -981,22 +1009,24 @@ def headline_mixture():
     return X, W64, W128
 
 
-@pytest.mark.parametrize("mode", ["mixed", "fast", "precise"])
-def test_headline_mixture_20_iterations(oa, headline_mixture, mode):
+@pytest.mark.parametrize("mode,one_launch", [("mixed", False), ("fast", False), ("precise", False), ("mixed", True), ("fast", True)])
+def test_headline_mixture_20_iterations(oa, headline_mixture, mode, one_launch, monkeypatch):
     """the headline shape (BASELINE.json configs[2]) on ill-conditioned mixture-like input for 20 iterations, every
     arithmetic mode, against the reference's own complex64 arithmetic (oracle, reference-faithful form): as close to it as
-    its distance from the complex128 result (the floor) allows"""
+    its distance from the complex128 result (the floor) allows.  one_launch: through cov_update_kernel (see above)."""
     X, W64, W128 = headline_mixture
     K = 2
     floor = orc.rel_err(W64, W128)
+    _one_launch_env(oa, monkeypatch, (X.shape[0], X.shape[1], X.shape[2], K), one_launch)
     oa.set_precision(mode)
     try:
         Y, W = oa.overiva(X, n_src=K, n_iter=20, proj_back=False, return_filters=True)
     finally:
         oa.set_precision("auto")
+        oa.release_cached_buffers()
     e64, e128 = orc.rel_err(W, W64), orc.rel_err(W, W128)
     eY = orc.rel_err(Y, _demix(X, W128))
-    _log(test="headline20", fixture="T4000F2048M8K2 mixture", model="laplace", n_iter=20, input="c64", mode=mode, W_vs_c128=e128,
+    _log(test="headline20" + ("-one-launch" if one_launch else ""), fixture="T4000F2048M8K2 mixture", model="laplace", n_iter=20, input="c64", mode=mode, W_vs_c128=e128,
          Y_vs_c128=eY, W_vs_ref_c64=e64, ref_c64_floor=floor)
     print(f"\n[parity] headline mixture 20 its {mode}: W vs reference-c64 {e64:.2e} (floor {floor:.2e}), vs c128 {e128:.2e}, Y {eY:.2e}")
     if mode == "fast":

@@ -183,6 +183,23 @@ def test_no_kernel_of_the_iteration_uses_scratch_memory():
     assert not bad, bad
 
 
+def test_occupancy_the_measured_kernels_were_built_for():
+    """register budgets that decide how many waves a SIMD holds (512 registers per lane and SIMD): the matrix-core covariance kernel
+    of configs[4] needs three workgroups per CU (<= 168 registers), the three-wave update kernel of configs[4] two workgroups
+    per CU (<= 256 with its accumulator registers) -- a build that crosses either line still passes every parity test and
+    loses 10-40 % of the stage"""
+    from overiva_amd import build
+
+    usage = build.kernel_usage()
+    if len(usage) < 100:
+        pytest.skip("resource remarks not available (library built without them)")
+    hm = [u for n, u in usage.items() if "cov_hmfma_kernelILb1ELb1ELb1E" in n]
+    rw = [u for n, u in usage.items() if "update_det16r_kernel" in n]
+    assert hm and rw
+    assert all(u["vgprs"] + u["agprs"] <= 168 for u in hm), hm
+    assert all(u["vgprs"] + u["agprs"] <= 256 for u in rw), rw
+
+
 def test_host_prefault_is_host_only_and_keeps_the_contents(lib):
     """oiva_host_prefault (csrc/host_io.hip: the copy-thread pool populating the pages of a destination) touches no device: it
     runs here.  Contents kept on an unaligned range, on a range shorter than a page, from four caller threads at once (the pool
