@@ -235,141 +235,168 @@ def _make_plan(oa, X, shape, mode, graph, resident=False):
     return plan
 
 
+# ---- roofline of the dominant (covariance) kernel ------------------------------------------------------------------------
+# One row per kernel family of csrc/kernels_cov*.hip: (applies(t, f, m, k, mode, fused), builder).  The first row that applies
+# names the kernel the plan dispatches for the shape (csrc/plan.hip::choose_cov_geom) and prices its launch: HBM-bound families
+# by SURVEY.md 8(d)'s algorithmic bytes, arithmetic-bound ones by the flops they ISSUE against the peak of the unit they issue to.
+_EVENT_NOTE = "avg_launch_ms is the event-bracketed stage: the weights pre-pass (~4-6 us) + the kernel + the gaps of the bracketing events"
+
+
+def _hbm_roof(kname, what, bytes_cov, cov_ms, note=None):
+    achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": f"{kname} ({what})", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms}
+    if note:
+        roof["note"] = note
+    return kname, roof
+
+
+def _flop_roof(kname, what, bound, peak, issued, cov_ms, shape, note, useful=None, parts=None, bytes_cov=None):
+    """arithmetic-bound family: achieved / frac = ISSUED flops per second against `peak`; beside them SURVEY 8d's naive complex
+    count (8 K M^2 T F; 268.4 GF at 16 x 16) and, where given, the useful count (Hermitian half, each product formed once)"""
+    t, f, m, k = shape
+    sec = cov_ms * 1e-3
+    naive = 8.0 * k * m * m * t * f
+    roof = {"bound": bound, "kernel": f"{kname} ({what})", "achieved": issued / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
+            "frac": issued / sec / 1e12 / peak, "issued_flops_per_launch": issued}
+    if parts:
+        roof["issued_matrix_flops_per_launch"], roof["issued_vector_flops_per_launch"] = parts
+    if useful is not None:
+        roof.update({"useful_flops_per_launch": useful, "useful_tflops": useful / sec / 1e12, "frac_useful": useful / sec / 1e12 / peak})
+    roof.update({"naive_complex_flops_per_launch": naive, "naive_complex_tflops": naive / sec / 1e12})
+    if useful is not None:
+        roof["frac_naive"] = naive / sec / 1e12 / peak
+    if bytes_cov is not None:
+        roof.update({"algorithmic_bytes_per_launch": bytes_cov, "hbm_gbs": bytes_cov / sec / 1e9})
+    roof.update({"avg_launch_ms": cov_ms, "traffic": None, "note": note})
+    return kname, roof
+
+
+def _useful_flops(t, f, m, k):
+    return ((m * (m - 1) // 2) * (6.0 + 4.0 * k) + m * (3.0 + 2.0 * k)) * t * f     # Hermitian half, products formed once
+
+
+def _roof_cov_update(t, f, m, k, mode, cov_ms):
+    # covariance + per-bin update of the same bins in ONE launch (csrc/kernels_cov_update.hip): the float64 partials stay in LDS --
+    # the 8 F K M^2 bytes SURVEY 8d counts for V are not written -- and W_hat (complex64 + complex128) and Cx are read, W_hat
+    # written: 8 T F M + 4 T K + F M^2 (8 + 16 + 8 + 8 + 16)
+    kname = "cov_update_kernel<double>" if mode != "fast" else "cov_update_kernel<float>"
+    return _hbm_roof(kname, "weighted spatial covariance of all sources in one pass AND the per-bin IP1 solve / normalisation / "
+                            "orthogonal-constraint update of the same bins in one launch, overiva.py:158-190",
+                     8 * t * f * m + 4 * t * k + f * m * m * 56, cov_ms,
+                     "the launch ends with the latency-bound per-bin chain of its four bins per workgroup (5-6 us during which nothing streams); "
+                     "the covariance kernel it replaces (cov_dma_kernel<8, 2>, $OIVA_COV_UPDATE=0) takes 97-99 us for 526.4 MB = 0.67 of the "
+                     "peak and is followed by update_bg_kernel (12.8 us)")
+
+
+def _roof_stream8(t, f, m, k, mode, cov_ms):
+    # up to 8 channels: one pass over X for all sources (two per pass of cov_dma), HBM-bound
+    if mode == "precise":
+        kname = f"cov_pair64_kernel<{min(k, 2)}, false>" if m == 8 else f"cov_kernel<{m}, {min(k, 2)}, false, double>"
+    else:
+        kname = "cov_pair32_kernel<false>" if m == 8 and k >= 3 else f"cov_dma_kernel<{m}, {min(k, 2)}>"
+    return _hbm_roof(kname, "weighted spatial covariance of all sources in one pass, overiva.py:179", cov_algorithmic_bytes(t, f, m, k), cov_ms,
+                     _EVENT_NOTE if kname.startswith(("cov_pair64", "cov_pair32")) else None)
+
+
+def _roof_quad(t, f, m, k, mode, cov_ms):
+    # 9..16 channels, few sources: the Hermitian half on the vector ALU, four lanes per (bin, frame), one pass over X per two sources
+    # (9 / 11 / 13 / 15 channels: the kernels of the next even count on a zero-padded copy of X; bytes stay the algorithmic ones)
+    kname = f"cov_quad_kernel<{min(k, 2)}, false>"
+    return _hbm_roof(kname, "weighted spatial covariance, two sources per pass over X, overiva.py:179",
+                     cov_algorithmic_bytes(t, f, m, k) + (-(-k // 2) - 1) * 8 * t * f * m, cov_ms,
+                     "co-limited by the vector ALU: 512 real FMAs per (bin, frame, source pair) at 16 channels against 128 at 8")
+
+
+def _roof_hmfma(t, f, m, k, mode, cov_ms):
+    # the sources on the fp32 matrix cores (csrc/kernels_cov_hmfma.hip): per bin and 4 frames mc + 1 v_mfma_f32_16x16x4_f32 (16 at 16
+    # channels: the 256 real numbers of the Hermitian half exactly), 2048 flops each whatever k, and the vector instructions forming the
+    # Hermitian products; bound by fp32 arithmetic -- matrix and vector instructions share the 157.3 TFLOP/s ALUs
+    mc = m + m % 2
+    mfma = (16 if mc == 16 else mc + 1) * 2048.0 / 4 * t * f
+    pk = mc == 16 and os.environ.get("OIVA_HMFMA_PK", "1") != "0"
+    # (16 channels: the partners from LDS, a product pair = two PACKED instructions of 256 flop slots -- 2 + 4 plain instructions for
+    #  the diagonal and the shared group of distance 8, 14 packed ones -- instead of 34 plain ones of 128)
+    valu = ((6 * 128.0 + 14 * 256.0) if pk else (2 + 4 * (mc // 2)) * 128.0) / 4 * t * f
+    kname = f"cov_hmfma_kernel<{'true' if mc == 16 else 'false'}, true, {'true' if pk else 'false'}>"
+    return _flop_roof(kname, "weighted spatial covariance of all sources in one pass, the sources on the fp32 matrix cores, overiva.py:179", "fp32",
+                      MFMA_F32_PEAK_TFLOPS, mfma + valu, cov_ms, (t, f, m, k),
+                      "achieved / frac count ISSUED flops (matrix instructions 2048 each, vector instructions 128) against the 157.3 TFLOP/s spec "
+                      "peak, which on CDNA4 the fp32 matrix and vector instructions SHARE (measured: their times add); useful = Hermitian half "
+                      "with each product formed once; naive = SURVEY 8d's 8 K M^2 T F.  " + _EVENT_NOTE,
+                      useful=_useful_flops(t, f, m, k), parts=(mfma, valu), bytes_cov=cov_algorithmic_bytes(t, f, m, k))
+
+
+def _roof_half16(t, f, m, k, mode, cov_ms):
+    # the Hermitian half on the vector ALU, 32 lanes per (bin, frame), every source in one pass: bound by fp32 arithmetic
+    np_ = 4 if k <= 8 else (6 if k <= 12 else 8)            # source PAIRS per lane of the instantiation
+    issued = 160.0 * (2 + 2 * np_) * 4.0 * t * f            # 160 complex entry slots per (bin, frame) x packed instructions x 4 flop slots
+    floor_ms = 32.0 * (10 + 10 * np_) * t * f / 64 / 1024 * 2.0e-6      # 1024 SIMDs, 2.0 ns per packed instruction and SIMD (tools/pkbench.hip)
+    kname = f"cov_half16_kernel<{np_}, false>"
+    return _flop_roof(kname, "weighted spatial covariance of all sources in one pass on the packed-fp32 vector ALU, overiva.py:179", "fp32",
+                      MFMA_F32_PEAK_TFLOPS, issued, cov_ms, (t, f, m, k),
+                      "achieved / frac count ISSUED flop slots of the packed vector ALU against the 157.3 TFLOP/s spec peak (vector = matrix peak on "
+                      "CDNA4; the planar matrix-core form needs 2.8x the multiply-adds and measured 1.69 ms at 16 x 16); useful = Hermitian half with "
+                      "each product formed once; naive = SURVEY 8d's 8 K M^2 T F.  Self-measured issue ceiling, for orientation only: 2.0 ns per "
+                      f"packed instruction and SIMD (tools/pkbench.hip) = {floor_ms:.3f} ms for this launch",
+                      useful=_useful_flops(t, f, m, k), bytes_cov=cov_algorithmic_bytes(t, f, m, k))
+
+
+def _roof_hmfma64(t, f, m, k, mode, cov_ms):
+    # the sources on the fp64 matrix cores (cov_hmfma64_kernel): 17 v_mfma_f64_16x16x4_f64 per bin and 4 frames + 2 + 8 x 6 float64 vector
+    # instructions per lane (conversions and moves not counted); fp64 matrix peak = fp64 vector peak = 78.6 TFLOP/s
+    mfma = 17 * 2048.0 / 4 * t * f
+    valu = (2 + 4 * 8) * 128.0 / 4 * t * f
+    return _flop_roof("cov_hmfma64_kernel", "weighted spatial covariance of all sources in one pass, float64, the sources on the fp64 matrix cores, "
+                      "overiva.py:179", "fp64", FP64_VECTOR_PEAK_TFLOPS, mfma + valu, cov_ms, (t, f, m, k),
+                      "issued float64 flops (matrix instructions 2048 each, vector multiplies / FMAs 128) against the 78.6 TFLOP/s fp64 peak (matrix = "
+                      "vector on MI355X); the float64 vector-ALU kernel it replaces at 9..16 sources measured 2.04 ms at 16 x 16",
+                      parts=(mfma, valu), bytes_cov=cov_algorithmic_bytes(t, f, m, k))
+
+
+def _roof_half16_f64(t, f, m, k, mode, cov_ms):
+    # the 32-lane form with float64 sums of exact products, four or eight sources per pass: bound by the float64 rate of the vector ALU
+    # (14 conversions + 20 + 10 * sources float64 instructions per lane and frame)
+    ns = 4 if k <= 4 else 8
+    passes = -(-k // ns)
+    floor_ms = 32.0 * (14 + 20 + 10 * ns) * passes * t * f / 64 / 1024 * 2.2e-6      # 2.2 ns per float64 instruction and SIMD (tools/pkbench.hip)
+    issued = 32.0 * (20 + 10 * ns) * 2.0 * passes * t * f  # float64 FMA slots x 2 flops (conversions not counted)
+    kname = f"cov_half16f64_kernel<{ns}>"
+    return _flop_roof(kname, f"weighted spatial covariance, {ns} sources per pass over X, float64 on the vector ALU, overiva.py:179", "fp64",
+                      FP64_VECTOR_PEAK_TFLOPS, issued, cov_ms, (t, f, m, k),
+                      "float64 FMA slots of the vector ALU against its 78.6 TFLOP/s spec peak; the fp64 matrix-core form it replaces measured 3.1 ms at "
+                      f"16 x 16.  Self-measured issue ceiling, for orientation only: 2.2 ns per float64 instruction and SIMD = {floor_ms:.3f} ms",
+                      bytes_cov=cov_algorithmic_bytes(t, f, m, k) + (passes - 1) * 8 * t * f * m)
+
+
+def _roof_planar(t, f, m, k, mode, cov_ms):
+    # the planar matrix-core form: 3 MFMAs of 16x16x4 per 4 frames and source
+    kname = "cov_mfma16_kernel<double, 16>" if mode == "precise" else "cov_mfma16_kernel<float, 16>"
+    return _flop_roof(kname, "planar v_mfma_f32_16x16x4_f32, overiva.py:179", "mfma", MFMA_F32_PEAK_TFLOPS, 6.0 * k * m * m * t * f, cov_ms, (t, f, m, k),
+                      "achieved/frac count ISSUED matrix-core flops; the naive-complex figure is algorithmic speed only; " + _EVENT_NOTE)
+
+
+def _hmfma_on():
+    return os.environ.get("OIVA_COV_HMFMA", "1") != "0"
+
+
+_COV_FAMILIES = (
+    (lambda t, f, m, k, mode, fused: m <= 8 and fused, _roof_cov_update),
+    (lambda t, f, m, k, mode, fused: m <= 8, _roof_stream8),
+    (lambda t, f, m, k, mode, fused: mode != "precise" and (k <= 2 or (k <= 4 and mode == "mixed")), _roof_quad),
+    (lambda t, f, m, k, mode, fused: mode != "precise" and k >= 9 and m + m % 2 >= 10 and _hmfma_on(), _roof_hmfma),
+    (lambda t, f, m, k, mode, fused: mode != "precise" and k > 4, _roof_half16),
+    (lambda t, f, m, k, mode, fused: mode == "precise" and k >= 9 and m + m % 2 == 16 and _hmfma_on(), _roof_hmfma64),
+    (lambda t, f, m, k, mode, fused: mode == "precise" and k >= 3, _roof_half16_f64),
+    (lambda t, f, m, k, mode, fused: True, _roof_planar),
+)
+
+
 def _cov_roofline(shape, mode, cov_ms, fused=False):
     t, f, m, k = shape
-    if m <= 8 and fused:
-        # covariance + per-bin update of the same bins in ONE launch (csrc/kernels_cov_update.hip): the float64 partials stay in
-        # LDS -- the 8 F K M^2 bytes SURVEY 8d counts for V are not written -- and W_hat (complex64 + complex128) and Cx are read,
-        # W_hat written: 8 T F M + 4 T K + F M^2 (8 + 16 + 8 + 8 + 16)
-        bytes_cov = 8 * t * f * m + 4 * t * k + f * m * m * 56
-        achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
-        kname = "cov_update_kernel<double>" if mode != "fast" else "cov_update_kernel<float>"
-        return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass AND the per-bin IP1 solve / normalisation / "
-                                                 "orthogonal-constraint update of the same bins in one launch, overiva.py:158-190)",
-                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                       "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
-                       "note": "the launch ends with the latency-bound per-bin chain of its four bins per workgroup (5-6 us during which "
-                               "nothing streams); the covariance kernel it replaces (cov_dma_kernel<8, 2>, $OIVA_COV_UPDATE=0) takes 97-99 us "
-                               "for 526.4 MB = 0.67 of the peak and is followed by update_bg_kernel (12.8 us)"}
-    if m <= 8:
-        bytes_cov = cov_algorithmic_bytes(t, f, m, k)
-        achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
-        if mode == "precise":
-            kname = f"cov_pair64_kernel<{min(k, 2)}, false>" if m == 8 else f"cov_kernel<{m}, {min(k, 2)}, false, double>"
-        else:
-            kname = "cov_pair32_kernel<false>" if m == 8 and k >= 3 else f"cov_dma_kernel<{m}, {min(k, 2)}>"
-        roof = {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, overiva.py:179)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms}
-        if kname.startswith(("cov_pair64", "cov_pair32")):
-            roof["note"] = "avg_launch_ms is the event-bracketed stage: the weights pre-pass (~4 us) + the kernel + the gaps of the bracketing events"
-        return kname, roof
-    # (9 / 11 / 13 / 15 channels: the kernels of the next even count on a zero-padded copy of X; bytes stay the algorithmic ones)
-    if mode != "precise" and (k <= 2 or (k <= 4 and mode == "mixed")):
-        # the Hermitian half on the vector ALU, four lanes per (bin, frame): one pass over X per two sources
-        bytes_cov = cov_algorithmic_bytes(t, f, m, k) + (-(-k // 2) - 1) * 8 * t * f * m
-        achieved = bytes_cov / (cov_ms * 1e-3) / 1e9
-        kname = f"cov_quad_kernel<{min(k, 2)}, false>"
-        return kname, {"bound": "hbm", "kernel": f"{kname} (weighted spatial covariance, two sources per pass over X, overiva.py:179)",
-                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                       "algorithmic_bytes_per_launch": bytes_cov, "avg_launch_ms": cov_ms,
-                       "note": "co-limited by the vector ALU: 512 real FMAs per (bin, frame, source pair) at 16 channels against 128 at 8"}
-    mc = m + m % 2
-    if mode != "precise" and k >= 9 and mc >= 10 and os.environ.get("OIVA_COV_HMFMA", "1") != "0":
-        # the sources on the fp32 matrix cores (csrc/kernels_cov_hmfma.hip): per bin and 4 frames mc + 1 v_mfma_f32_16x16x4_f32 (16 at
-        # 16 channels, round 5: the 256 real numbers of the Hermitian half exactly)
-        # (2048 flops each, all 16 source rows whatever k) and 2 + 4 (mc / 2) vector instructions forming the Hermitian products
-        # (64 lanes x 2 flop slots); bound by fp32 arithmetic -- matrix and vector instructions share the 157.3 TFLOP/s ALUs
-        bytes_cov = cov_algorithmic_bytes(t, f, m, k)
-        mfma = (16 if mc == 16 else mc + 1) * 2048.0 / 4 * t * f
-        pk = mc == 16 and os.environ.get("OIVA_HMFMA_PK", "1") != "0"
-        # (16 channels, round 5: the partners from LDS, a product pair = two PACKED instructions of 256 flop slots -- 2 + 4 plain
-        #  instructions for the diagonal and the shared group of distance 8, 14 packed ones -- instead of 34 plain ones of 128)
-        valu = ((6 * 128.0 + 14 * 256.0) if pk else (2 + 4 * (mc // 2)) * 128.0) / 4 * t * f
-        issued = mfma + valu
-        useful = ((m * (m - 1) // 2) * (6.0 + 4.0 * k) + m * (3.0 + 2.0 * k)) * t * f     # Hermitian half, products formed once
-        naive = 8.0 * k * m * m * t * f                         # naive complex count (268.4 GF at 16 x 16)
-        sec = cov_ms * 1e-3
-        kname = f"cov_hmfma_kernel<{'true' if mc == 16 else 'false'}, true, {'true' if pk else 'false'}>"
-        return kname, {"bound": "fp32", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, the sources on the fp32 matrix cores, overiva.py:179)",
-                       "achieved": issued / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                       "issued_flops_per_launch": issued, "issued_matrix_flops_per_launch": mfma, "issued_vector_flops_per_launch": valu,
-                       "useful_flops_per_launch": useful, "naive_complex_flops_per_launch": naive,
-                       "useful_tflops": useful / sec / 1e12, "frac_useful": useful / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                       "naive_complex_tflops": naive / sec / 1e12, "frac_naive": naive / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                       "algorithmic_bytes_per_launch": bytes_cov, "hbm_gbs": bytes_cov / sec / 1e9, "avg_launch_ms": cov_ms, "traffic": None,
-                       "note": "achieved / frac count ISSUED flops (matrix instructions 2048 each, vector instructions 128) against the 157.3 "
-                               "TFLOP/s spec peak, which on CDNA4 the fp32 matrix and vector instructions SHARE (measured: their times add); "
-                               "useful = Hermitian half with each product formed once; naive = SURVEY 8d's 8 K M^2 T F.  avg_launch_ms is the "
-                               "event-bracketed stage: the weights pre-pass (~6 us) + the kernel + the gaps of the bracketing events"}
-    if mode != "precise" and k > 4:
-        # the Hermitian half on the vector ALU, 32 lanes per (bin, frame), every source in one pass: bound by fp32 arithmetic
-        # (cfg5's roofline is the 157.3 TFLOP/s fp32 peak, which the packed vector ALU shares with the matrix cores)
-        bytes_cov = cov_algorithmic_bytes(t, f, m, k)
-        np_ = 4 if k <= 8 else (6 if k <= 12 else 8)            # source PAIRS per lane of the instantiation
-        slots = 160.0                                           # complex entry slots per (bin, frame): 32 lanes x 5 (136 entries of the half)
-        issued = slots * (2 + 2 * np_) * 4.0 * t * f            # packed instructions x 4 flop slots each (v_pk_mul_f32 uses 2 of its 4)
-        useful = ((m * (m - 1) // 2) * (6.0 + 4.0 * k) + m * (3.0 + 2.0 * k)) * t * f     # Hermitian half, products formed once
-        naive = 8.0 * k * m * m * t * f                         # naive complex count (268.4 GF at 16 x 16)
-        sec = cov_ms * 1e-3
-        instr = 32.0 * (10 + 10 * np_) * t * f / 64             # packed wave-instructions per launch
-        floor_ms = instr / 1024 * 2.0e-6                        # 1024 SIMDs, 2.0 ns per packed instruction and SIMD (tools/pkbench.hip)
-        kname = f"cov_half16_kernel<{np_}, false>"
-        return kname, {"bound": "fp32", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass on the packed-fp32 vector ALU, overiva.py:179)",
-                       "achieved": issued / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                       "issued_flops_per_launch": issued, "useful_flops_per_launch": useful, "naive_complex_flops_per_launch": naive,
-                       "useful_tflops": useful / sec / 1e12, "frac_useful": useful / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                       "naive_complex_tflops": naive / sec / 1e12, "frac_naive": naive / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                       "algorithmic_bytes_per_launch": bytes_cov, "hbm_gbs": bytes_cov / sec / 1e9, "avg_launch_ms": cov_ms, "traffic": None,
-                       "note": "achieved / frac count ISSUED flop slots of the packed vector ALU against the 157.3 TFLOP/s spec peak (vector = matrix "
-                               "peak on CDNA4; the planar matrix-core form needs 2.8x the multiply-adds and measured 1.69 ms at 16 x 16); useful = "
-                               "Hermitian half with each product formed once; naive = SURVEY 8d's 8 K M^2 T F.  Self-measured issue ceiling, for "
-                               f"orientation only: 2.0 ns per packed instruction and SIMD (tools/pkbench.hip) = {floor_ms:.3f} ms for this launch"}
-    if mode == "precise" and k >= 9 and mc == 16 and os.environ.get("OIVA_COV_HMFMA", "1") != "0":
-        # the sources on the fp64 matrix cores (cov_hmfma64_kernel): 17 v_mfma_f64_16x16x4_f64 per bin and 4 frames + 2 + 8 x 6
-        # float64 vector instructions (conversions, products) per lane; fp64 matrix peak = fp64 vector peak = 78.6 TFLOP/s
-        bytes_cov = cov_algorithmic_bytes(t, f, m, k)
-        mfma = 17 * 2048.0 / 4 * t * f
-        valu = (2 + 4 * 8) * 128.0 / 4 * t * f                  # float64 multiplies / FMAs (conversions and moves not counted)
-        issued = mfma + valu
-        naive = 8.0 * k * m * m * t * f
-        sec = cov_ms * 1e-3
-        kname = "cov_hmfma64_kernel"
-        return kname, {"bound": "fp64", "kernel": f"{kname} (weighted spatial covariance of all sources in one pass, float64, the sources on the fp64 matrix cores, overiva.py:179)",
-                       "achieved": issued / sec / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                       "issued_flops_per_launch": issued, "issued_matrix_flops_per_launch": mfma, "issued_vector_flops_per_launch": valu,
-                       "naive_complex_flops_per_launch": naive, "naive_complex_tflops": naive / sec / 1e12,
-                       "algorithmic_bytes_per_launch": bytes_cov, "hbm_gbs": bytes_cov / sec / 1e9, "avg_launch_ms": cov_ms, "traffic": None,
-                       "note": "issued float64 flops (matrix instructions 2048 each, vector multiplies / FMAs 128) against the 78.6 TFLOP/s fp64 peak "
-                               "(matrix = vector on MI355X); the float64 vector-ALU kernel it replaces at 9..16 sources measured 2.04 ms at 16 x 16"}
-    if mode == "precise" and k >= 3:
-        # the same lanes with float64 sums of exact products, four or eight sources per pass: bound by the float64 rate of the
-        # vector ALU (14 conversions + 20 + 10 * sources float64 instructions per lane and frame); peak: 78.6 TFLOP/s fp64 vector
-        ns = 4 if k <= 4 else 8
-        passes = -(-k // ns)
-        bytes_cov = cov_algorithmic_bytes(t, f, m, k) + (passes - 1) * 8 * t * f * m
-        instr = 32.0 * (14 + 20 + 10 * ns) * passes * t * f / 64
-        floor_ms = instr / 1024 * 2.2e-6                       # 2.2 ns per float64 instruction and SIMD (tools/pkbench.hip)
-        issued = 32.0 * (20 + 10 * ns) * 2.0 * passes * t * f  # float64 FMA slots x 2 flops (conversions not counted)
-        naive = 8.0 * k * m * m * t * f
-        sec = cov_ms * 1e-3
-        kname = f"cov_half16f64_kernel<{ns}>"
-        return kname, {"bound": "fp64", "kernel": f"{kname} (weighted spatial covariance, {ns} sources per pass over X, float64 on the vector ALU, overiva.py:179)",
-                       "achieved": issued / sec / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                       "issued_flops_per_launch": issued, "naive_complex_flops_per_launch": naive, "naive_complex_tflops": naive / sec / 1e12,
-                       "algorithmic_bytes_per_launch": bytes_cov, "hbm_gbs": bytes_cov / sec / 1e9, "avg_launch_ms": cov_ms, "traffic": None,
-                       "note": "float64 FMA slots of the vector ALU against its 78.6 TFLOP/s spec peak; the fp64 matrix-core form it replaces measured "
-                               f"3.1 ms at 16 x 16.  Self-measured issue ceiling, for orientation only: 2.2 ns per float64 instruction and SIMD = {floor_ms:.3f} ms"}
-    naive = 8.0 * k * m * m * t * f            # complex MACs counted as 8 real flops
-    issued = 6.0 * k * m * m * t * f           # what the planar form issues: 3 MFMAs of 16x16x4 per 4 frames and source
-    kname = "cov_mfma16_kernel<double, 16>" if mode == "precise" else "cov_mfma16_kernel<float, 16>"
-    return kname, {"bound": "mfma", "kernel": f"{kname} (planar v_mfma_f32_16x16x4_f32, overiva.py:179)",
-                   "achieved": issued / (cov_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": issued / (cov_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                   "issued_flops_per_launch": issued, "naive_complex_flops_per_launch": naive,
-                   "naive_complex_tflops": naive / (cov_ms * 1e-3) / 1e12, "avg_launch_ms": cov_ms,
-                   "note": "achieved/frac count ISSUED matrix-core flops; the naive-complex figure is algorithmic speed only; "
-                           "avg_launch_ms is the event-bracketed stage (weights pre-pass of ~6 us + the matrix-core kernel)"}
+    for applies, build in _COV_FAMILIES:
+        if applies(t, f, m, k, mode, fused):
+            return build(t, f, m, k, mode, cov_ms)
 
 
 def _rates(steps, dts):
@@ -682,7 +709,21 @@ def run_sharded(args):
             # between.  W warm-up iterations, then exactly K timed ones
             if fused:
                 eng.plan.use_graph(True)
-            eng.plan.iterate(args.steps)
+            # the protocol of _time_plan, so that N = 1 through this leg and the single-GPU line agree: an untimed pass of the same K
+            # steps until >= 50 ms of iterations have run (the same number on every rank: rank 0's), then W, then K timed
+            global _PRE_PASS_STEPS
+            t_pre = time.perf_counter()
+            n_pre = 0
+            while True:
+                eng.plan.iterate(args.steps)
+                stream.synchronize()
+                n_pre += args.steps
+                go_on = [time.perf_counter() - t_pre < 0.05 and n_pre < 100000]
+                if world > 1:
+                    dist.broadcast_object_list(go_on, src=0)
+                if not go_on[0]:
+                    break
+            _PRE_PASS_STEPS = n_pre
             eng.plan.iterate(args.warmup)
             stream.synchronize()
             dist.barrier()
@@ -812,6 +853,8 @@ def run_sharded(args):
             out["config"]["parallelism"] = (f"bins sharded over {world} GPU(s); four kernels per iteration replayed from hipGraphs, the partial source "
                                             "powers exchanged inside the activation kernel by peer stores over xGMI (no collective, no host call in the loop)")
     out["cpu_baseline"] = None      # reported at N = 1 only
+    if resident or fused:
+        out["untimed_pre_pass_steps"] = _PRE_PASS_STEPS   # (as the single-GPU line: >= 50 ms of untimed iterations in front of the W warm-up steps)
     # a fast exchange that was asked for (or implied by `auto`) and refused is a DEGRADED run: said at the top level, not
     # only among the per-rank details
     degraded = None if (resident or fused or args.exchange in ("collective", "push")) else (fused_refused or resident_refused or "refused")
