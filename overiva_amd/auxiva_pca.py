@@ -31,7 +31,7 @@ def auxiva_pca(X, n_src=None, **kwargs):
     kwargs.pop("proj_back")                                                   # auxiva_pca.py:86
     kwargs.pop("return_filters", None)   # the reference would hand a tuple to projection_back and fail
 
-    precision = _ov.resolve_precision(dtype, n_chan)
+    precision = _ov.resolve_precision(dtype, n_chan, n_frames=n_frames)
     with Plan(n_frames, n_freq, n_chan, n_src, "laplace", device=_ov.get_device()) as full:
         full.set_precision(precision)
         full.set_x(X)

@@ -4,10 +4,11 @@
 Arithmetic (``set_precision``): device data (X, Y) is complex64 whatever the input dtype.  ``"auto"`` (default) follows
 the reference, which computes in the dtype of X (``overiva.py:89,126-131``): complex128 input runs ``"precise"`` -- the
 weighted covariance as float64 sums of exact float64 products and the per-bin algebra in float64 with W_hat carried in
-complex128, i.e. the reference's complex128 arithmetic applied to complex64-rounded data; complex64 input runs ``"mixed"``
--- float32 products and short float32 lane chains in the covariance pass, every longer sum and the per-bin algebra in
-float64: closer to the reference's complex128 result than the reference's own complex64 arithmetic is
-(``resolve_precision``).  ``"fast"`` is float32 in the per-bin algebra too:
+complex128, i.e. the reference's complex128 arithmetic applied to complex64-rounded data; complex64 input runs the same on
+short frame axes with up to 8 channels (the reference's own call sizes: it forms the covariances in complex128 there too,
+``overiva.py:179``) and ``"mixed"`` elsewhere -- float32 products and short float32 lane chains in the covariance pass, every
+longer sum and the per-bin algebra in float64: closer to the reference's complex128 result than the reference's own complex64
+arithmetic is (``resolve_precision``).  ``"fast"`` is float32 in the per-bin algebra too:
 1e-5 on well-conditioned input, a few times the reference's complex64 noise otherwise
 (tests/test_gpu_parity.py::test_fast_mode_accuracy).
 
@@ -42,17 +43,33 @@ def set_precision(mode):
     _precision = mode
 
 
-def resolve_precision(dtype, n_chan, mode=None, n_src=None):
+# frame axes up to this long count as short: the reference's own calls (4096-point frames of ~10 s of audio: 160-235 frames)
+SHORT_FRAME_AXIS = 256
+
+
+def resolve_precision(dtype, n_chan, mode=None, n_src=None, n_frames=None):
     """``"auto"`` follows the reference, which computes in the dtype of X (overiva.py:89,126,131): complex128 input ->
-    ``"precise"``; complex64 input -> ``"mixed"``: at every supported channel count the covariance pass hands float64 sums of
-    short float32 chains to the float64 per-bin algebra (up to 8 channels: csrc/kernels_cov.hip, kernels_cov_pair32.hip;
-    9..16 channels: kernels_cov_quad.hip with up to 4 sources, kernels_cov_half16.hip with 5..8, the fp32 matrix cores of
-    kernels_cov_hmfma.hip with 9..16 -- odd counts on a copy of X padded by one zero channel).
-    (``n_chan`` and ``n_src`` no longer matter; kept for callers.)"""
+    ``"precise"``.  complex64 input: the reference still forms every weighted covariance in complex128 (``r_inv`` is float64,
+    overiva.py:127-128,179) and rounds it once --
+
+    * up to 8 channels on a short frame axis (``n_frames <= SHORT_FRAME_AXIS``, every call of the reference's own scripts): the
+      same, ``"precise"`` -- float64 sums of exact float64 products, float64 per-bin algebra.  Those passes are bound by
+      latency, not arithmetic: 0-3 % of the iteration up to 5 channels, 3-18 % at 6-8 channels with up to 4 sources
+      (profiles/r05_stage_times_reference_shapes.log), and it removes the one i.i.d. row that float32 chains held 1.7 reference
+      floors from the complex128 result (round 5's ``NOISE_ROWS_OVER_ONE_FLOOR``).  (2, 6 and 8 channels with 1-2 sources whose
+      X fits on chip keep ``"mixed"`` and the X-resident kernel -- the float64 covariance exists there for 4 channels only --,
+      decided by ``_SingleDevice`` once the plan knows its geometry);
+    * everything else -> ``"mixed"``: float32 products and short float32 lane chains in the covariance pass, every longer sum
+      and the per-bin algebra in float64 (up to 8 channels: csrc/kernels_cov.hip, kernels_cov_pair32.hip; 9..16 channels:
+      kernels_cov_quad.hip with up to 4 sources, kernels_cov_half16.hip with 5..8, the fp32 matrix cores of
+      kernels_cov_hmfma.hip with 9..16 -- odd counts on a copy of X padded by one zero channel).
+    (``n_src`` does not matter; kept for callers.)"""
     mode = _precision if mode is None else mode
     if mode != "auto":
         return mode
     if np.dtype(dtype) != np.complex64:
+        return "precise"
+    if n_frames is not None and n_frames <= SHORT_FRAME_AXIS and n_chan <= 8:
         return "precise"
     return "mixed"
 
@@ -201,7 +218,9 @@ def overiva(
 
 def _solve(X, dtype, n_src, n_iter, proj_back, W0, model, init_eig, return_filters, callback):
     n_frames, n_freq, n_chan = X.shape
-    precision = resolve_precision(dtype, n_chan, n_src=n_src)
+    precision = resolve_precision(dtype, n_chan, n_src=n_src, n_frames=n_frames)
+    # (chosen by `auto` for a short frame axis, not asked for: may give way to the X-resident kernel's arithmetic, see _SingleDevice)
+    short_axis_auto = _precision == "auto" and np.dtype(dtype) == np.complex64 and precision == "precise"
     group = sharded.active_group()
     if group is not None and isinstance(X, DeviceX):
         raise ValueError("a device-resident X cannot be sharded over ranks: pass the host array")
@@ -209,7 +228,7 @@ def _solve(X, dtype, n_src, n_iter, proj_back, W0, model, init_eig, return_filte
         solver = sharded.BinShardedSolver(n_frames, n_freq, n_chan, n_src, model, group=group[0], precision=precision,
                                           exchange=group[1] if len(group) > 1 else None)
     else:
-        solver = _SingleDevice(n_frames, n_freq, n_chan, n_src, model, precision)
+        solver = _SingleDevice(n_frames, n_freq, n_chan, n_src, model, precision, prefer_resident=short_axis_auto)
     try:
         solver.set_x(X)
         solver.covariance()
@@ -284,24 +303,34 @@ class _SingleDevice:
     # 2048x4000x8 4.1k eager vs 4.5k replayed)
     GRAPH_MIN_ELEMENTS = 1 << 23
 
-    def __init__(self, T, F, M, K, model, precision="fast"):
+    def __init__(self, T, F, M, K, model, precision="fast", prefer_resident=False):
+        self.key = (get_device(), T, F, M, K)
+        resident_ok = os.environ.get("OIVA_RESIDENT", "1") != "0" and self.key not in _resident_gave_up
+        plan = None
+        if prefer_resident and precision == "precise" and M != 4 and resident_ok:
+            # `auto` picked the float64 covariance for a short frame axis; where the whole iteration runs as ONE launch with X on chip
+            # (2, 6, 8 channels, 1-2 sources + background) that kernel's arithmetic -- `mixed` -- stays: it has the float64 covariance
+            # for 4 channels only, and the four launches in `precise` are 1.4-1.9 times its time on those shapes
+            plan = Plan(T, F, M, K, model, device=get_device())
+            if plan.resident_info()["qualifies"]:
+                precision = "mixed"
         self.wdtype = np.complex64 if precision == "fast" else np.complex128
         self.precision = precision
-        self.key = (get_device(), T, F, M, K)
         # a plan of exactly this problem kept by an earlier call (see close()): its buffers, stream and captured graphs serve again
         self.cache_key = self.key + (model, precision)
         self.ok = False
         self.plan = _plan_cache.pop(self.cache_key, None)
         if self.plan is not None:
+            if plan is not None:
+                plan.close()
             return
-        self.plan = Plan(T, F, M, K, model, device=get_device())
+        self.plan = plan if plan is not None else Plan(T, F, M, K, model, device=get_device())
         self.plan.set_precision(precision)
         if T * F * M >= self.GRAPH_MIN_ELEMENTS:
             self.plan.use_graph(True)
         # the loop body as one persistent launch with X on chip wherever the shape qualifies (csrc/resident_kernel.inc; the
         # float64 covariance of `precise` exists there for 4 channels); $OIVA_RESIDENT=0 keeps the four-launch path
-        if ((precision != "precise" or M == 4) and os.environ.get("OIVA_RESIDENT", "1") != "0" and self.key not in _resident_gave_up
-                and self.plan.resident_info()["qualifies"]):
+        if (precision != "precise" or M == 4) and resident_ok and self.plan.resident_info()["qualifies"]:
             self.plan.set_resident(True)
 
     def set_x(self, X):

@@ -9,15 +9,16 @@ STFT input; the distance is ||a-b||_F / ||b||_F.
     the reference's complex128 result: ``1e-5``, scaled by ``amp / 10`` only where the reference itself amplifies rounding
     by more than 10 (fixture key ``amp_*`` = measured amplification of a relative input perturbation in the reference,
     tests/golden/make_golden.py); nothing is compared where it is chaotic (amp > 1e3, conftest.chaotic);
-  - complex64 input, every channel count (``mixed``: float32 products and lane chains, float64 sums and per-bin algebra),
+  - complex64 input: on frame axes up to 256 long with up to 8 channels ``auto`` runs ``precise`` too (round 6: the reference
+    forms those covariances in complex128 as well, overiva.py:179), except where the X-resident kernel keeps ``mixed`` (2, 6, 8
+    channels with 1-2 sources); elsewhere ``mixed`` (float32 products and lane chains, float64 sums and per-bin algebra) --
     against the reference's OWN complex64 result (``W_c64_*``): ``max(1e-5, 1.5 * floor)`` with floor = distance between
     the reference's complex64 and complex128 results -- the parity claim -- and against the complex128 result
     ``max(that bound, floor)``: never less accurate than the reference's own complex64 arithmetic (achieved: 0.1-0.9
     floors).  On the four rows where the reference's own complex64 run is not reproducible to 1e-3 under a last-bit change
     of X (conftest.c64_diverged, measured on the real reference: tests/golden/c64_jitter.npz) "floor" is replaced by that
-    jitter where it is larger -- see test_overiva_matches_reference.  One row (NOISE_ROWS_OVER_ONE_FLOOR: i.i.d. input,
-    gauss, 20 iterations, a row of pure amplified rounding noise, where the reference's complex128-formed covariances beat
-    float32 chains) lands 1.7 floors from the complex128 result and is held to 1.25 of the reference's own jitter there.
+    jitter where it is larger -- see test_overiva_matches_reference.  (Round 5's one exception -- fixture z, i.i.d., gauss, 20
+    iterations, 1.7 floors in ``mixed`` -- runs the float64 covariance now and needs none.)
 * ``fast`` arithmetic (float32 per-bin algebra too): 1e-5 on well-conditioned (i.i.d.) input; on mixture-like input a
   documented envelope of FAST_FLOORS reference floors -- an accuracy statement of that mode, not the parity claim.
 
@@ -39,7 +40,6 @@ TOL = 1e-5          # the north_star bound
 TOL_KERNEL = 3e-6   # single-kernel bound (one fp32 pass, no iteration feedback)
 # rows of pure amplified rounding noise where `mixed` lands MORE than one floor from the reference's complex128 result (see
 # test_overiva_matches_reference): each entry is a measured, documented exception, not a class
-NOISE_ROWS_OVER_ONE_FLOOR = {("z_iid", "gauss", 20)}
 TOL_KERNEL_F64 = 1e-12   # float64 accumulation of exact float32 products
 FAST_FLOORS = 6.0   # envelope of the float32 mode on ill-conditioned input, in reference-complex64 floors
 
@@ -339,9 +339,7 @@ def test_overiva_matches_reference(oa, golden, model, n_iter, dt):
     k64 = f"W_c64_{model}_{n_iter}"
     floor = orc.rel_err(golden[k64], ref128) if k64 in golden else None
     e64 = orc.rel_err(W, golden[k64]) if k64 in golden else None
-    from overiva_amd.overiva import resolve_precision
-
-    mode = resolve_precision(Xin.dtype, X.shape[2], n_src=K)
+    mode = oa.last_solver_info()["precision"]      # (what `auto` ran: overiva.resolve_precision + the X-resident rule)
     # One floor against the complex128 result, 1.5 against the complex64 one -- everywhere but on the four rows where the
     # reference's OWN complex64 run is not reproducible to 1e-3 (conftest.c64_diverged: its W moves by `jitter` when X changes
     # in the last bit; e_mix laplace 20: jitter 7.1e-3 = 4 floors).  There the yardstick is that jitter: nothing can be pinned
@@ -351,17 +349,10 @@ def test_overiva_matches_reference(oa, golden, model, n_iter, dt):
         yard = max(floor, c64_jitter(golden, model, n_iter))
     if mode == "mixed" and floor is not None:
         b128 = max(b128, yard)   # never less accurate than the reference's own complex64 arithmetic ...
-    # ... with ONE measured exception, found by the round-5 fixture z (160 frames x 40 bins x 8 channels / 3 sources): on its
-    # i.i.d. input, gauss model, 20 iterations, every float32 rounding is amplified some 300 times (the reference's complex64 W
-    # moves by 2.7e-5 = 1.4 floors when X changes in its last bit: the row is pure amplified rounding noise), and there the
-    # covariances decide: the reference forms them in complex128 and rounds once (overiva.py:179, r_inv is float64), `mixed`
-    # adds float32 chains of T / (4 splits) frames -- about three times that rounding.  Measured W vs c128 (floor 1.9e-5):
-    # 1 split 4.7e-5, 2 (the plan's choice, and 4) 3.2e-5, 3: 2.2e-5, 7: 1.7e-5; `precise` 9.6e-8.  The row is held to 1.25 / 1.5
-    # of the reference's own jitter and must BE such a row (jitter > 1.25 floors); no other row of the 390 uses this.
-    if mode == "mixed" and (golden["_id"], model, n_iter) in NOISE_ROWS_OVER_ONE_FLOOR:
-        jit = c64_jitter(golden, model, n_iter)
-        assert jit is not None and jit > 1.25 * floor
-        b128, yard = max(b128, 1.25 * jit), jit
+    # (Round 5 carried ONE exception here -- fixture z, 160 frames x 40 bins x 8 channels / 3 sources, i.i.d., gauss, 20
+    #  iterations: W 1.7 floors from complex128 in `mixed`, because the reference forms the covariances in complex128 and rounds
+    #  once (overiva.py:179) where `mixed` adds float32 chains.  Round 6: `auto` runs the float64 covariance on short frame axes
+    #  with up to 8 channels -- the row is 1e-7 from complex128 now and the exception list is gone.)
     _log(test="e2e", fixture=golden["_id"], model=model, n_iter=n_iter, input=dt, mode=mode, W_vs_c128=e128,
          Y_vs_c128=eY, W_vs_ref_c64=e64, ref_c64_floor=floor, amp=_amp(golden, model, n_iter), bound_c128=b128,
          ref_c64_jitter=c64_jitter(golden, model, n_iter))
@@ -524,14 +515,13 @@ def test_odd_shapes_against_oracle(oa, shape, model):
     """channel counts without a golden fixture (incl. the 9..16-channel covariance kernels) and every form of the per-bin update
     -- structured chain (1-2 sources + background), Gram form (3 and more sources + background), maintained inverse (determined, up
     to 8 and 9..16 channels) -- in the default arithmetic"""
-    from overiva_amd.overiva import resolve_precision
-
     T, F, M, K = shape
     X = orc.synth_iid(T, F, M, seed=sum(shape))
-    mode = resolve_precision(X.dtype, M, n_src=K)
     Yr, Wr = orc.overiva_staged(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
+    mode = "mixed"
     try:
         Y, W = oa.overiva(X, n_src=K, n_iter=4, proj_back=True, model=model, return_filters=True)
+        mode = oa.last_solver_info()["precision"]
         eW, eY = orc.rel_err(W, Wr), orc.rel_err(Y, Yr)
     except np.linalg.LinAlgError:
         # a W_hat^H V that is singular in complex64 arithmetic (gauss, 2 bins x 15 channels: the weights 1 / r leave V to a

@@ -102,15 +102,22 @@ def test_product_never_imports_the_oracle():
 
 
 def test_default_arithmetic_rule():
-    """`auto` (overiva.py:89,126,131: the reference computes in the dtype of X): complex128 -> precise; complex64 -> mixed
+    """`auto` (overiva.py:89,126,131: the reference computes in the dtype of X): complex128 -> precise; complex64 -> precise on a
+    short frame axis with up to 8 channels (overiva.py:179: the reference forms those covariances in complex128 too), else mixed,
     where the covariance pass hands float64 sums of short float32 chains to the float64 per-bin algebra"""
-    from overiva_amd.overiva import resolve_precision as rp
+    from overiva_amd.overiva import SHORT_FRAME_AXIS, resolve_precision as rp
 
     assert rp(np.complex128, 4, "auto", 2) == "precise" and rp(np.complex128, 16, "auto", 2) == "precise"
     assert all(rp(np.complex64, m, "auto", k) == "mixed" for m in range(1, 9) for k in range(1, m + 1))
     assert all(rp(np.complex64, m, "auto", k) == "mixed" for m in range(9, 17) for k in (1, 2, 4, 5, m))
     assert rp(np.complex64, 16, "auto") == "mixed"
     assert rp(np.complex64, 16, "fast", 2) == "fast" and rp(np.complex128, 4, "mixed", 2) == "mixed"
+    # the frame axis decides for complex64 input of up to 8 channels
+    assert SHORT_FRAME_AXIS == 256
+    assert all(rp(np.complex64, m, "auto", 2, n_frames=t) == "precise" for m in range(1, 9) for t in (2, 160, 235, 256))
+    assert all(rp(np.complex64, m, "auto", 2, n_frames=t) == "mixed" for m in range(1, 9) for t in (257, 1000, 4000))
+    assert all(rp(np.complex64, m, "auto", m, n_frames=160) == "mixed" for m in range(9, 17))
+    assert rp(np.complex64, 8, "mixed", 2, n_frames=160) == "mixed" and rp(np.complex64, 8, "fast", 2, n_frames=160) == "fast"
 
 
 def test_shard_bounds():

@@ -11,18 +11,18 @@ def f(x):
 
 rows = [json.loads(line) for line in open(sys.argv[1])]
 e2e = [r for r in rows if r["test"] == "e2e"]
-print("# Achieved parity errors (MI355X, round 5)\n")
+print("# Achieved parity errors (MI355X, round 6)\n")
 print("Source: `tests/test_gpu_parity.py` run with `OIVA_PARITY_LOG` on the GPU box; distances are relative Frobenius")
 print("norms.  `floor` = distance between the REAL reference's complex64 and complex128 results on the fixture")
 print("(stored by `tests/golden/make_golden.py`); `amp` = the reference's own amplification of a 1e-12 input")
-print("perturbation.  Default arithmetic (`auto`): complex64 input runs `mixed` at every channel count (float32 products and lane")
-print("chains, float64 sums and per-bin algebra; the X-resident kernel where the shape qualifies); complex128 input runs")
-print("`precise`.  `fast` = float32 per-bin algebra too.\n")
+print("perturbation.  Default arithmetic (`auto`): complex128 input runs `precise`; complex64 input runs `precise` too on frame axes")
+print("up to 256 long with up to 8 channels (the reference forms those covariances in complex128 as well, overiva.py:179; 2, 6, 8")
+print("channels with 1-2 sources whose X fits on chip keep `mixed` and the X-resident kernel), `mixed` elsewhere (float32 products")
+print("and lane chains, float64 sums and per-bin algebra).  The `mode` column says which ran.  `fast` = float32 per-bin algebra too.\n")
 print("## overiva(), complex64 input (the default mode of that input), final W after n_iter iterations\n")
 print("`jitter` = how far the reference's own complex64 W moves when X changes in its last bit (tests/golden/c64_jitter.npz); rows")
-print("whose jitter exceeds 1e-3 are held to max(floor, jitter) instead of the floor (marked *).  One row lands MORE than one floor")
-print("from the complex128 result (marked +: z_iid gauss 20 -- i.i.d. input, a row of pure amplified rounding noise, where the")
-print("reference's complex128-formed covariances beat float32 chains; tests/test_gpu_parity.py NOISE_ROWS_OVER_ONE_FLOOR).\n")
+print("whose jitter exceeds 1e-3 are held to max(floor, jitter) instead of the floor (marked *).  Rows more than one floor from the")
+print("complex128 result would be marked +: round 5 had one (z_iid gauss 20, `mixed`), round 6 none.\n")
 print("| fixture | model | n_iter | amp | mode | reference c64 floor | c64 jitter | W vs reference-c64 | in floors | W vs c128 | in floors | Y vs c128 | fast: W vs c128 | in floors |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 key = lambda r: (r["fixture"], r["model"], r["n_iter"])
