@@ -534,6 +534,18 @@ def run_single(args):
     assert np.all(np.isfinite(W))
     splits = plan.cov_splits()
     one_launch = plan.set_fuse_cov_update(None)
+    digests = None
+    if args.w_digest > 0:
+        import hashlib
+
+        from overiva_amd.sharded import shard_bounds
+        plan.set_w(None)
+        plan.iterate(args.w_digest)
+        Wd = plan.get_w(np.complex64 if args.precision == "fast" else np.complex128)
+        b = shard_bounds(F, args.digest_shards)
+        digests = [hashlib.sha256(np.ascontiguousarray(Wd[b[g]:b[g + 1]]).tobytes()).hexdigest()[:16] for g in range(args.digest_shards)]
+        if args.w_dump:
+            np.save(os.path.join(args.w_dump, "w_rank0of1.npy"), Wd)
     plan.close()
     cov_ms = stages["weighted_cov"] / args.steps
     per_step = {k: v / args.steps for k, v in stages.items()}
@@ -548,6 +560,8 @@ def run_single(args):
     roofline.update({"stage_ms_per_step": per_step, "event_timed_ms_per_step": total_ms / args.steps, "cov_splits": splits})
     out = result_line(args, 1, dt)
     out["untimed_pre_pass_steps"] = pre_pass        # (see _time_plan: >= 50 ms of untimed iterations in front of the W warm-up steps)
+    if digests is not None:
+        out["w_digest_shards"] = {"iterations": args.w_digest, "shards": args.digest_shards, "sha256_16": digests}
     if more:
         out.update(_rates(args.steps, [dt] + more))
     out["roofline"] = roofline
@@ -826,6 +840,23 @@ def run_sharded(args):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     W = eng.get_w()
     assert np.all(np.isfinite(W))
+    if args.w_digest > 0:
+        # N iterations from the identity start through the transport that was timed; this rank's bins
+        import hashlib
+        with eng.stream_ctx():
+            eng.set_w(None)
+            stream.synchronize()
+            dist.barrier()
+            if resident or fused:
+                eng.plan.iterate(args.w_digest)
+            else:
+                for _ in range(args.w_digest):
+                    step()
+            stream.synchronize()
+        Wd = np.ascontiguousarray(eng.get_w())
+        breakdown["w_digest"] = hashlib.sha256(Wd.tobytes()).hexdigest()[:16]
+        if args.w_dump:
+            np.save(os.path.join(args.w_dump, f"w_rank{rank}of{world}.npy"), Wd)
     one_launch = eng.plan.set_fuse_cov_update(None)
     exchange_name, exchange_fallback = xchg.name, getattr(xchg, "fallback_reason", None)
     xchg.close()
@@ -1020,6 +1051,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the sharded path (nccl = RCCL; tests use gloo)")
     ap.add_argument("--single-device", action="store_true",
                     help="tests on a 1-GPU box: every rank uses GPU 0 (needs --backend gloo: RCCL refuses two ranks on one device)")
+    ap.add_argument("--w-digest", type=int, default=0, metavar="N",
+                    help="after the measurement: N iterations from the identity start and sha256 of the demixing matrices, per rank (N > 1 GPUs: "
+                         "ranks.per_rank_stage_ms[*].w_digest) or per shard of --digest-shards equal bin ranges (N = 1: w_digest_shards) -- "
+                         "equal shards through the four-launch path give the bits of one GPU")
+    ap.add_argument("--digest-shards", type=int, default=1)
+    ap.add_argument("--w-dump", default=None, metavar="DIR", help="with --w-digest: also save those matrices as DIR/w_rank<r>of<N>.npy (tests)")
     ap.add_argument("--launch-timeout", type=int, default=600,
                     help="seconds a sharded run may take before its watchdog ends it with a non-zero exit code")
     ap.add_argument("--launch-grace", type=int, default=60, help=argparse.SUPPRESS)
