@@ -17,9 +17,9 @@ $B --force-sharded --no-cpu --no-other-mode > "$OUT/bench_sharded_1rank.json" 2>
 # kernel-trace statistics of the bench command
 # (the headline workload alone, so that a kernel's average is the average over ITS launches of that workload: the secondary
 #  configs run the same kernel instantiations on other shapes -- those go to stats_configs)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_headline" -o s -- $B --steps 20 --warmup 3 --no-cpu --no-configs > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_configs" -o s -- $B --steps 20 --warmup 3 --no-cpu --no-other-mode > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_cfg5" -o s -- $B --config cfg5 --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_headline" -o s -- $B --steps 20 --warmup 3 --no-cpu --no-configs > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_configs" -o s -- $B --steps 20 --warmup 3 --no-cpu --no-other-mode > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_cfg5" -o s -- $B --config cfg5 --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
 
 # counters, headline shape, fast mode, eager launches
 i=0
@@ -29,13 +29,13 @@ for c in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" \
          "SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_headline/p$i" -o p -- $B $HEAD > /dev/null 2>&1
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_headline/p$i" -o p -- $B $HEAD > /dev/null 2>&1
 done
 # HBM traffic of the precise mode (float64 covariance on the vector ALU, float64 per-bin algebra)
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i + 1))
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_precise/p$i" -o p -- $B $HEAD --precision precise > /dev/null 2>&1
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_precise/p$i" -o p -- $B $HEAD --precision precise > /dev/null 2>&1
 done
 # counters, cfg5 (default arithmetic: the covariance kernel with the sources on the fp32 matrix cores)
 i=0
@@ -43,25 +43,25 @@ for c in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
          "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS" "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT"; do
     i=$((i + 1))
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_cfg5/p$i" -o p -- $B --config cfg5 $HEAD > /dev/null 2>&1
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_cfg5/p$i" -o p -- $B --config cfg5 $HEAD > /dev/null 2>&1
 done
 # 16 channels / 2 sources (the four-lanes-per-(bin, frame) covariance kernel), default arithmetic of that shape
 $B --config m16k2 --no-cpu > "$OUT/bench_m16k2.json" 2> "$OUT/bench_m16k2.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_m16k2" -o s -- $B --config m16k2 --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_m16k2" -o s -- $B --config m16k2 --steps 20 --warmup 3 --no-cpu > /dev/null 2>&1
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_m16k2/p$i" -o p -- $B --config m16k2 $HEAD > /dev/null 2>&1
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_m16k2/p$i" -o p -- $B --config m16k2 $HEAD > /dev/null 2>&1
 done
 # the X-resident kernel: HBM traffic per launch of 50 iterations (X once + the exchange words), shard of the headline shape and configs[1]
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i + 1))
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_resident_shard8/p$i" -o p -- python3 $ROOT/tools/resident_case.py 4000 256 8 2 50 > /dev/null 2>&1
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_resident_cfg2/p$i" -o p -- python3 $ROOT/tools/resident_case.py 1000 513 4 2 50 > /dev/null 2>&1
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_resident_shard8/p$i" -o p -- python3 $ROOT/tools/resident_case.py 4000 256 8 2 50 > /dev/null 2>&1
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_resident_cfg2/p$i" -o p -- python3 $ROOT/tools/resident_case.py 1000 513 4 2 50 > /dev/null 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_resident" -o s -- python3 $ROOT/tools/resident_case.py 4000 256 8 2 50 > "$OUT/resident_shard8.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_resident" -o s -- python3 $ROOT/tools/resident_case.py 4000 256 8 2 50 > "$OUT/resident_shard8.log" 2>&1
 # (round 4) the shard step at several launch lengths, single rank and loop-back world 8; the fixed cost of a launch; every
 # workgroup's phase boundaries; the 2- and 4-GPU shards through the exchange inside the activation kernel (loop-back)
 python3 $ROOT/tools/shard_step.py > "$OUT/shard_step.log" 2>&1
@@ -79,6 +79,14 @@ python3 $ROOT/tools/stage_times_reference_shapes.py > "$OUT/stage_times_referenc
 python3 $ROOT/tools/shard_fused_ab.py > "$OUT/shard_fused_ab.log" 2>&1
 python3 $ROOT/tools/sweep_shape_splits.py > "$OUT/sweep_shape_splits.log" 2>&1
 (cd $ROOT && rm -f "$OUT/parity.jsonl" && OIVA_PARITY_LOG="$OUT/parity.jsonl" python3 -m pytest tests/test_gpu_parity.py -m gpu -q > "$OUT/parity_pytest.log" 2>&1)
+# (round 6) configs[4]: the per-bin update in its two forms, the new kernel's roles alone and workgroup 0's timeline (variant builds of
+# tools/build_variant.py, when present)
+OIVA_DET16_ROWS=0 timeout 200 python3 $ROOT/tools/r6/det16_ab.py > "$OUT/det16_ab.log" 2>&1
+timeout 200 python3 $ROOT/tools/r6/det16_ab.py >> "$OUT/det16_ab.log" 2>&1
+for v in r16onlya r16onlyb; do
+    [ -f $ROOT/overiva_amd/liboveriva_hip_$v.so ] && OIVA_LIB=$ROOT/overiva_amd/liboveriva_hip_$v.so timeout 200 python3 $ROOT/tools/r6/det16_roles.py >> "$OUT/det16_ab.log" 2>&1
+done
+[ -f $ROOT/overiva_amd/liboveriva_hip_r16trace.so ] && OIVA_LIB=$ROOT/overiva_amd/liboveriva_hip_r16trace.so timeout 200 python3 $ROOT/tools/r6/det16_trace.py > "$OUT/det16_trace.log" 2>&1
 # keep what travels back small: drop the raw kernel traces of the --stats runs
 find "$OUT" -name "*_kernel_trace.csv" -path "*stats_*" -delete
 find "$OUT" -name "*_agent_info.csv" -delete
