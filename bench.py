@@ -493,6 +493,21 @@ def _secondary_config(torch, oa, dev, name, args):
             best = out["fused_loopback"]
         except Exception as e:
             out["fused_loopback"] = {"error": f"{type(e).__name__}: {e}"}
+    if name == "cfg5" and mode == "mixed" and os.environ.get("OIVA_HMFMA_PART32") is None:
+        # the opt-in form of this config: the covariance kernel's partial blocks cross HBM as float32 (half the bytes that bound the
+        # per-bin update; one more rounding per block: DESIGN.md 3) -- reported beside `value`, never as it
+        os.environ["OIVA_HMFMA_PART32"] = "1"
+        try:
+            plan = _make_plan(oa, X, shape, mode, True)
+            dt32, _, stages32, more32 = _time_plan(plan, args, repeats=args.repeats)
+            plan.close()
+            out["float32_partial_blocks"] = {"value": args.steps / dt32, "unit": "iterations/s", "ms_per_step": dt32 / args.steps * 1e3,
+                                             **_rates(args.steps, [dt32] + more32), "stage_ms_per_step": {k: v / args.steps for k, v in stages32.items()},
+                                             "what": "$OIVA_HMFMA_PART32=1: not the default arithmetic of overiva()"}
+        except Exception as e:
+            out["float32_partial_blocks"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            del os.environ["OIVA_HMFMA_PART32"]
     out.update({k: best[k] for k in ("value_median", "value_min", "value_max", "repeats")})
     out["unit"] = "iterations/s"
     return out
@@ -581,6 +596,9 @@ def run_single(args):
                 lb = out["configs"][name].get("resident_loopback8", {}).get("value")
                 if lb:
                     out["config"][f"iterations_per_s_{name}_loopback8"] = lb
+                f32 = out["configs"][name].get("float32_partial_blocks", {}).get("value")
+                if f32:
+                    out["config"][f"iterations_per_s_{name}_float32_partial_blocks_optin"] = f32
             except Exception as e:  # a secondary shape must not cost the headline line
                 out["configs"][name] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()

@@ -105,7 +105,7 @@ using hm_ic = std::integral_constant<int, I>;
 // instructions share the ALUs and their times add).  Needs a split's frames + 35 within 4 GB of X; else the flat form.
 template <bool M16, bool BUF, bool PK>
 __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __restrict__ X, const float* __restrict__ Wt,
-                                                              double* __restrict__ Vpart, int T, int F, int M, int Mv, int K, int tc) {
+                                                              double* __restrict__ Vpart, int T, int F, int M, int Mv, int K, int tc, int part32) {
     constexpr int NG = M16 ? 16 : 17;
     constexpr int kRingBytes = kWaves * kHmStages * kHmStage;
     constexpr int kScratchBytes = 16 * 8 * kBlock;       // reduction scratch: 4 groups x 2 sets of 16-byte vectors per thread
@@ -433,7 +433,12 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
     // and re / im, is wave-uniform now (scalar registers), no longer compile-time.
     f32x4* lds4 = reinterpret_cast<f32x4*>(ring);          // [group of the round][set][thread]
     const int NA = Mv * Mv;
-    double* vout = Vpart + (((size_t)blockIdx.y * F + f0) * K + 4 * q) * NA;
+    // (round 6) part32: the block leaves as float32 -- each value the float64 sum of 8 float32 chains of <= 128 frames, rounded ONCE
+    // (6e-8 relative, a tenth of what its chains carry; the update adds the splits' blocks in float64 as before): half the bytes
+    // written here and read by the per-bin update, which at 16 x 16 is bound by exactly those bytes (277 MB = 46 us of 66)
+    const size_t vbase = (((size_t)blockIdx.y * F + f0) * K + 4 * q) * NA;
+    double* vout = Vpart + vbase;
+    float* vout32 = reinterpret_cast<float*>(Vpart) + vbase;
 #pragma unroll
     for (int g0 = 0; g0 < NG; g0 += 4) {
         __syncthreads();
@@ -475,7 +480,13 @@ __global__ __launch_bounds__(kBlock, 2) void cov_hmfma_kernel(const float2* __re
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (4 * q + r < K) vout[(size_t)r * NA + pos] = neg ? -s[r] : s[r];
+            if (4 * q + r < K) {
+                const double v = neg ? -s[r] : s[r];
+                if (part32)                              // (uniform)
+                    vout32[(size_t)r * NA + pos] = (float)v;
+                else
+                    vout[(size_t)r * NA + pos] = v;
+            }
     }
 }
 
@@ -697,13 +708,13 @@ hipError_t launch_cov_hmfma(hipStream_t s, const float2* X, const float* Wt, dou
     const char* pkv = std::getenv("OIVA_HMFMA_PK");
     const bool pk = !(pkv && pkv[0] == '0');
     if (M == 16) {
-        if (buf && pk) return launch_dominant(cov_hmfma_kernel<true, true, true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
-        if (buf) return launch_dominant(cov_hmfma_kernel<true, true, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
-        if (pk) return launch_dominant(cov_hmfma_kernel<true, false, true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
-        return launch_dominant(cov_hmfma_kernel<true, false, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+        if (buf && pk) return launch_dominant(cov_hmfma_kernel<true, true, true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc, g.part32);
+        if (buf) return launch_dominant(cov_hmfma_kernel<true, true, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc, g.part32);
+        if (pk) return launch_dominant(cov_hmfma_kernel<true, false, true>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc, g.part32);
+        return launch_dominant(cov_hmfma_kernel<true, false, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc, g.part32);
     }
-    if (buf) return launch_dominant(cov_hmfma_kernel<false, true, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
-    return launch_dominant(cov_hmfma_kernel<false, false, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc);
+    if (buf) return launch_dominant(cov_hmfma_kernel<false, true, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc, g.part32);
+    return launch_dominant(cov_hmfma_kernel<false, false, false>, grid, block, 0, s, X, Wt, Vpart, T, F, M, Mv, K, g.tc, g.part32);
 }
 
 }  // namespace oiva

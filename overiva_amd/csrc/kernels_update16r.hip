@@ -167,6 +167,7 @@ __device__ __forceinline__ void spin_until(const int* flag, int value) {
 #endif
 }
 
+template <typename VT>
 __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
     __shared__ LdsR s;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -196,35 +197,41 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
     if (wave != 0) {
         // =============== waves 1, 2: V_s of the sources b, b + 2, ... summed over the splits and eliminated ===============
         const int b = wave - 1;
-        const double* vbase = static_cast<const double*>(a.Vpart);
+        // (VT: float64 partials, or -- the matrix-core covariance kernel, round 6 -- float32 ones: each the float64 sum of 8 float32
+        //  chains rounded once; either way added here in float64, in split order)
+        const VT* vbase = static_cast<const VT*>(a.Vpart);
         const size_t vstride = (size_t)a.F * M * NA;
         const int nsplit = a.nsplit;
-        const unsigned blk_bytes = (unsigned)NA * 8u;
-        constexpr int kPieces = kBinsPerWaveR * N * N / 2 / 64;        // 16-byte pieces per lane and split (8): piece lane + 64 j
-        // piece lane + 64 j of a split: bin j >> 1 of the workgroup, 1 KB (j & 1) of its block -- as the lane's byte offset from the
+        const unsigned blk_bytes = (unsigned)NA * (unsigned)sizeof(VT);
+        constexpr int kElems = 16 / (int)sizeof(VT);                   // values per 16-byte piece (2 | 4)
+        constexpr int kSub = N * N / kElems / 64;                      // 64-piece (1 KB) parts of a bin's block of 256 values (2 | 1)
+        constexpr int kPieces = kBinsPerWaveR * kSub;                  // pieces per lane and split (8 | 4): piece lane + 64 j
+        // piece lane + 64 j of a split: bin j / kSub of the workgroup, 1 KB j % kSub of its block -- as the lane's byte offset from the
         // block of the workgroup's first bin (bins past F: the last bin's block again), so that a split of a source has ONE uniform
         // base address and a load is one instruction (scalar base + 32-bit lane offset)
         const int f_first = blockIdx.x * kBinsPerWaveR;
         unsigned poff[kPieces];
 #pragma unroll
         for (int j = 0; j < kPieces; ++j) {
-            const int fr = f_first + (j >> 1);
-            const unsigned off = (unsigned)((j & 1) * 64 + lane) * 16u;
-            // lanes past the block re-read its start (their sums are not used); odd M: the last piece runs 8 bytes over (the next block, or the buffer's slack)
-            poff[j] = (unsigned)((fr < a.F ? fr : a.F - 1) - f_first) * (unsigned)(M * NA * 8) + (off < blk_bytes ? off : 0u);
+            const int fr = f_first + j / kSub;
+            const unsigned off = (unsigned)((j % kSub) * 64 + lane) * 16u;
+            // lanes past the block re-read its start (their sums are not used); odd M: the last piece runs over (the next block, or the buffer's slack)
+            poff[j] = (unsigned)((fr < a.F ? fr : a.F - 1) - f_first) * (unsigned)(M * NA * (int)sizeof(VT)) + (off < blk_bytes ? off : 0u);
         }
         const char* wg_base = reinterpret_cast<const char*>(vbase + (size_t)f_first * M * NA);
         // The partials travel in two batches of (at most) two splits, 64 registers: splits 0, 1 of the next source of this wave are
         // requested before the elimination of the current one and added in the middle of it, where splits 2, 3 are requested; those
         // are added when the elimination is over.  (All four at once: 128 registers in flight, 324 with the rest -- one wave per SIMD.)
-        double2 P[2][kPieces], acc[kPieces];
+        using piece_t = std::conditional_t<sizeof(VT) == 8, double2, float4>;
+        piece_t P[2][kPieces];
+        double acc[kPieces][kElems];
         auto load_pair = [&](int src, int sp0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (sp0 + u < nsplit) {                     // (uniform)
-                    const char* sbase = wg_base + ((size_t)(sp0 + u) * vstride + (size_t)src * NA) * 8;
+                    const char* sbase = wg_base + ((size_t)(sp0 + u) * vstride + (size_t)src * NA) * sizeof(VT);
 #pragma unroll
-                    for (int j = 0; j < kPieces; ++j) P[u][j] = *reinterpret_cast<const double2*>(sbase + poff[j]);
+                    for (int j = 0; j < kPieces; ++j) P[u][j] = *reinterpret_cast<const piece_t*>(sbase + poff[j]);
                 }
         };
         // acc (+)= the batch, in split order (first: acc = split 0)
@@ -235,12 +242,14 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
                 if (sp0 + u < nsplit) {
 #pragma unroll
                     for (int j = 0; j < kPieces; ++j) {
-                        if (sp0 + u == 0) {
-                            acc[j] = P[u][j];
+                        double v[kElems];
+                        if constexpr (sizeof(VT) == 8) {
+                            v[0] = P[u][j].x, v[1] = P[u][j].y;
                         } else {
-                            acc[j].x += P[u][j].x;
-                            acc[j].y += P[u][j].y;
+                            v[0] = (double)P[u][j].x, v[1] = (double)P[u][j].y, v[2] = (double)P[u][j].z, v[3] = (double)P[u][j].w;
                         }
+#pragma unroll
+                        for (int e = 0; e < kElems; ++e) acc[j][e] = sp0 + u == 0 ? v[e] : acc[j][e] + v[e];
                     }
                 }
         };
@@ -277,7 +286,10 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
             lds_wait();
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < kPieces; ++j) reinterpret_cast<double2*>(vs)[lane + 64 * j] = make_double2(acc[j].x * invT, acc[j].y * invT);
+            for (int j = 0; j < kPieces; ++j)
+#pragma unroll
+                for (int e = 0; e < kElems; e += 2)
+                    reinterpret_cast<double2*>(vs)[((lane + 64 * j) * kElems + e) / 2] = make_double2(acc[j][e] * invT, acc[j][e + 1] * invT);
             const int nxt = claim();
             const bool more = nxt < M;
             if (more) load_pair(nxt, 0);                   // in flight while this source is eliminated
@@ -531,13 +543,15 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
 // the determined float64 update of 9..16 channels with one matrix row per lane; false: not this kernel's case
 bool update_det16r_applies(const UpdateArgs& a) {
     static const bool on = [] { const char* v = getenv("OIVA_DET16_ROWS"); return !(v && v[0] == '0'); }();
-    return on && a.K == a.M && a.M > 8 && a.M <= 16 && a.use_double && !a.init_only && a.layout == 0 && a.vpart_f64 && a.nsplit <= kMaxSplitsR;
+    return on && a.K == a.M && a.M > 8 && a.M <= 16 && a.use_double && !a.init_only && a.layout == 0 && a.nsplit <= kMaxSplitsR;
 }
 
 hipError_t launch_update_det16r(hipStream_t s, const UpdateArgs& a) {
     const dim3 grid((a.F + kBinsPerWaveR - 1) / kBinsPerWaveR);
-    if (!a.vpart_f64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(update_det16r_kernel, grid, dim3(192), 0, s, a);
+    if (a.vpart_f64)
+        hipLaunchKernelGGL(update_det16r_kernel<double>, grid, dim3(192), 0, s, a);
+    else
+        hipLaunchKernelGGL(update_det16r_kernel<float>, grid, dim3(192), 0, s, a);
     return hipGetLastError();
 }
 

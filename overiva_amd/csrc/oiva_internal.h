@@ -72,6 +72,7 @@ struct CovGeom {
     int pair32 = 0; // 8 channels, >= 3 sources, float32: kernels_cov_pair32.hip (32 bins per workgroup, four sources per pass)
     int pad = 0;  // odd channel count on the vector-ALU kernels: they read the copy of X padded to M + 1 channels
     int quad = 0; // 10/12/14/16 channels, few sources, float32: the vector-ALU kernel of kernels_cov_quad.hip (float64 partials)
+    int part32 = 0; // hmfma, float32 arithmetic: the partial blocks leave as float32 (each the float64 sum of its chains, rounded once)
 };
 struct PowGeom {
     int nb;       // bin batches of 64 (grid.x)

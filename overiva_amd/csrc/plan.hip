@@ -184,7 +184,8 @@ struct oiva_plan {
     // element type of the covariance partials: the vector-ALU kernels (<= 8 channels) always sum their float32 lane
     // chains across lanes in float64 and store float64 partials; the 9..16-channel matrix-core kernel stores its
     // accumulator type
-    bool vpart_f64() const { return cov_f64() || M <= 8 || cov.quad || cov.half16; }
+    bool vpart_f64() const { return vpart_f64_of(cov); }
+    bool vpart_f64_of(const CovGeom& g) const { return cov_f64() || M <= 8 || g.quad || (g.half16 && !g.part32); }
     int use_graph = 0;
     // OGIVE (ive.py): per-bin state, allocated by oiva_plan_ogive_begin
     OgiveState og{};
@@ -323,6 +324,15 @@ void choose_cov_geom(oiva_plan* p, int nsplit_req) {
         }
         g.tc = round_up(ceil_div(p->T, nsplit), g.hmfma ? 32 : 16);
         g.nsplit = ceil_div(p->T, g.tc);
+        // (round 6, opt-in: $OIVA_HMFMA_PART32=1, read whenever the geometry is chosen) the float32 matrix-core kernel hands its
+        // partial blocks over as float32 -- half the bytes the per-bin update is bound by at 16 x 16 (update 66 -> 50 us, iteration
+        // 931 -> 903 us) for one more rounding per block: W moves by 1e-8 on i.i.d. input and by 3e-6 .. 1e-5 (0.3-0.5 reference
+        // floors) on a 16-source mixture at full size, and the fixtures of <= 1024 frames land up to twice as far from the
+        // complex128 result (tools/r6/part32_ab.py, tools/r6/NOTES.md).  Not the default: parity first.
+        if (g.hmfma && !p->cov_f64()) {
+            const char* pv = std::getenv("OIVA_HMFMA_PART32");
+            g.part32 = pv && pv[0] == '1';
+        }
         p->cov = g;
         return;
     }
@@ -989,9 +999,10 @@ int oiva_plan_covariance(oiva_plan* p) {
     if (rcp) return rcp;
     CovGeom g = p->cov;
     g.kc = 1;
+    g.part32 = 0;          // (one "source": never the matrix-core kernel)
     // unit weights, one "source": partials land in Vpart laid out as [nsplit][F][1][M*M]
     HIP_TRY(launch_cov(p->stream, p->X, p->X_pad, nullptr, nullptr, nullptr, p->model, 0, p->Vpart, p->cov_f64(), p->T, p->F, p->M, 1, g));
-    HIP_TRY(launch_sum_parts(p->stream, p->Vpart, p->vpart_f64(), g.nsplit, p->Cx, (long long)p->F * p->M * p->M, 1. / (double)p->T));
+    HIP_TRY(launch_sum_parts(p->stream, p->Vpart, p->vpart_f64_of(g), g.nsplit, p->Cx, (long long)p->F * p->M * p->M, 1. / (double)p->T));
     p->have_cx = true;
     return OIVA_OK;
 }

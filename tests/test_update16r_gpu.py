@@ -105,3 +105,23 @@ def test_rows_kernel_more_than_four_splits_falls_back(oa):
             W[splits] = p.get_w(np.complex128)
     for splits in (8, 32):
         assert np.all(np.isfinite(W[splits])) and orc.rel_err(W[splits], W[4]) < 1e-5
+
+
+def test_float32_partial_blocks_opt_in(oa, monkeypatch):
+    """$OIVA_HMFMA_PART32=1 (read when a plan chooses its geometry): cov_hmfma_kernel stores its partial blocks as float32 -- each value
+    the float64 sum of its chains rounded once -- and both forms of the update add them in float64: W after three iterations within
+    1e-6 of the float64-block run on i.i.d. input, with 1, 2 and 4 frame splits and an odd channel count (blocks of odd length)"""
+    for (T, F, M, splits) in ((512, 12, 16, 1), (2048, 9, 16, 2), (4096, 5, 16, 4), (1024, 6, 13, 2)):
+        X = orc.synth_iid(T, F, M, seed=T + M)
+        W = {}
+        for part in ("0", "1"):
+            monkeypatch.setenv("OIVA_HMFMA_PART32", part)
+            with oa.Plan(T, F, M, M, "laplace") as p:
+                p.set_precision("mixed")
+                p.set_x(X); p.covariance(); p.set_w(None)
+                p.set_cov_splits(splits)
+                p.iterate(3)
+                W[part] = p.get_w(np.complex128)
+        e = orc.rel_err(W["1"], W["0"])
+        print(f"\n[float32 partial blocks] {T}x{F}x{M}, {splits} splits: W vs float64 blocks {e:.1e}")
+        assert np.all(np.isfinite(W["1"])) and 0 < e < 1e-6
