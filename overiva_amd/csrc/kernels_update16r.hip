@@ -150,6 +150,7 @@ struct LdsR {
     int ready[kFacBufs], consumed[kFacBufs];            // sources handed over / taken, + 1, per buffer
     int claim;                                          // next source nobody eliminates yet
     int sq_done;                                        // wave 0 has C in registers: the last buffer is free
+    int w_requested;                                    // wave 0 has requested W_hat: the eliminating waves may load
     // [buffer = source mod 3][plane][lane]: the recorded elimination of V_s.  Three buffers: the eliminating waves run up to three
     // sources ahead of the chain, which starts late (behind the inversion of W_hat^H).  The LAST one doubles as `sq` of that
     // inversion -- the inverse's rows, filed under the column they pivoted, [bin][16][16] --: source 2 waits for sq_done.
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
         s.consumed[threadIdx.x] = 0;
         s.claim = 0;
         s.sq_done = 0;
+        s.w_requested = 0;
     }
     __syncthreads();
 
@@ -271,6 +273,9 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
             if (lane == 0) nx = atomicAdd(&s.claim, 1);
             return __builtin_amdgcn_readfirstlane(nx);
         };
+        // (wave 0's 8 KB of W_hat first: behind the 32 KB every eliminating wave requests at once -- 34 MB on the chip -- its loads
+        //  took 13 us to come back, and the chain starts only when the inversion is done)
+        spin_until(&s.w_requested, 1);
         int src = claim();
         if (src < M) {
             load_pair(src, 0);
@@ -377,6 +382,10 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
             A[c] = {vr, -vi};
         }
     }
+    // (the loads above are requested, not yet back: the flag is set in program order behind their issue)
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane == 0) *const_cast<volatile int*>(&s.w_requested) = 1;
+    __builtin_amdgcn_sched_barrier(0);
     if (a.wscale != nullptr && i < M) {
         const double sc = 1.0 / (double)a.wscale[i];
 #pragma unroll
@@ -392,11 +401,13 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
         bool used = false;
         Z piv = {1., 0.};
         int mycol = i;
-        auto step = [&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            if (c == 8) R16_STAMP(66);
-            if (c == 9) R16_STAMP(72);
-            const Z aic = A[c];
+        // One step, on the column that sits in register U: the loop below runs four steps and then moves every register four places
+        // down, so that the code of a step exists FOUR times, not sixteen -- the sixteen unrolled steps (190 instructions each,
+        // executed once per workgroup, by all workgroups at the same moment) ran at 44 cycles per instruction: instruction-cache
+        // misses, 24 us for the inversion; as a loop 10 us.
+        auto step = [&](auto uc, int c) {
+            constexpr int U = decltype(uc)::value;
+            const Z aic = A[U];
             const float mag = (float)(aic.re * aic.re + aic.im * aic.im);
             unsigned key = used ? 0u : ((__float_as_uint(mag) & ~31u) | 16u | (unsigned)(15 - i));
             // the maximum over the 16 lanes of the row: row_ror:1, 2, 4, 8 as the DPP control of v_max_u32 itself (two wait states
@@ -412,16 +423,13 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
                          : "+v"(key));
             const int p = 15 - (int)(key & 15u);
             const bool mine = i == p;
-            if (c == 8) R16_STAMP(67);
             wave_lds_sync();
-            if (c == 8) R16_STAMP(68);
             if (mine) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) s.prow[g][j] = j == c ? Z{1., 0.} : A[j];
+                for (int j = 0; j < N; ++j) s.prow[g][j] = j == U ? Z{1., 0.} : A[j];
                 s.ppiv[g] = aic;
             }
             wave_lds_sync();
-            if (c == 8) R16_STAMP(69);
             // (every read of the pivot row requested before the first is waited for: hipcc's own schedule kept two in flight and paid
             //  nine LDS round trips per step)
             const Z apc = s.ppiv[g];
@@ -429,10 +437,6 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
 #pragma unroll
             for (int j = 0; j < N; ++j) row[j] = s.prow[g][j];
             __builtin_amdgcn_sched_barrier(0);
-            if (c == 8) {
-                lds_wait();
-                R16_STAMP(70);
-            }
             used = used || mine;
             mycol = mine ? c : mycol;
             piv.re = mine ? apc.re : piv.re;
@@ -440,16 +444,24 @@ __global__ __launch_bounds__(192) void update_det16r_kernel(UpdateArgs a) {
             Z fct = zmul(aic, zinv_fast(apc));
             fct.re = mine ? 0. : fct.re;
             fct.im = mine ? 0. : fct.im;
-            A[c] = {mine ? 1. : 0., 0.};
+            A[U] = {mine ? 1. : 0., 0.};
 #pragma unroll
             for (int j = 0; j < N; ++j) zsubmul(A[j], fct, row[j]);
         };
-#define OIVA_R16_STEP(c) \
-    if (c < M) step(std::integral_constant<int, c>{});
-        OIVA_R16_STEP(0) OIVA_R16_STEP(1) OIVA_R16_STEP(2) OIVA_R16_STEP(3) OIVA_R16_STEP(4) OIVA_R16_STEP(5) OIVA_R16_STEP(6)
-        OIVA_R16_STEP(7) OIVA_R16_STEP(8) OIVA_R16_STEP(9) OIVA_R16_STEP(10) OIVA_R16_STEP(11) OIVA_R16_STEP(12)
-        OIVA_R16_STEP(13) OIVA_R16_STEP(14) OIVA_R16_STEP(15)
-#undef OIVA_R16_STEP
+        R16_STAMP(66);
+#pragma unroll 1
+        for (int c0 = 0; c0 < N; c0 += 4) {
+            if (c0 + 0 < M) step(std::integral_constant<int, 0>{}, c0 + 0);
+            if (c0 + 1 < M) step(std::integral_constant<int, 1>{}, c0 + 1);
+            if (c0 + 2 < M) step(std::integral_constant<int, 2>{}, c0 + 2);
+            if (c0 + 3 < M) step(std::integral_constant<int, 3>{}, c0 + 3);
+            // registers four places down (column c0 + 4 to register 0, ...): after the fourth round they are back in place
+            Z t0 = A[0], t1 = A[1], t2 = A[2], t3 = A[3];
+#pragma unroll
+            for (int j = 0; j + 4 < N; ++j) A[j] = A[j + 4];
+            A[N - 4] = t0, A[N - 3] = t1, A[N - 2] = t2, A[N - 1] = t3;
+        }
+        R16_STAMP(72);
         wave_lds_sync();
         Z* sq = &s.fac[kFacBufs - 1][0][0];                 // (the last hand-over buffer, not yet in use)
         {
