@@ -10,7 +10,11 @@ namespace {
 // Source activation, reference overiva.py:152-155:
 //   R[t,k] = 2 sqrt(p) (laplace) | p / F_total (gauss), p = sum over parts in part order (bin batch, or rank then
 //   batch), associated in the canonical blocks described in the kernel: a sharded run with equal shards on 64-bin
-//   batches gets the same bits as the single-GPU run.  The loads of a group of 8 parts are issued together.  Each block (kBlock frames of one source) also leaves the float64 sum of its r per
+//   batches gets the same bits as the single-GPU run -- of r; of W too where the plans also split the frame axis of the covariance
+//   pass alike.  (16 channels with more than 4 sources: the 64-bin parts themselves come from power_lds_kernel where
+//   a plan's bin count is a multiple of 64 and from power_mfma_kernel otherwise, which add a part's 64 bins in different orders: a
+//   shard of ragged size -- a world that does not divide the 64-bin batches -- agrees with one GPU to rounding only)
+//   The loads of a group of 8 parts are issued together.  Each block (kBlock frames of one source) also leaves the float64 sum of its r per
 //   source behind R (rsum_offset_floats): the consumers derive gamma (overiva.py:158) from those few values
 //   (gamma_of) instead of re-reducing the T activations in every workgroup.
 // Canonical sum over `count` parts starting at part `first` of one (frame, source) element -- the parts in blocks of `bs`
