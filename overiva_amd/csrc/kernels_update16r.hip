@@ -19,11 +19,14 @@
 // u / y_s (again row_newbcast), and u = C e_s -- the 16 registers of lane s -- reaches the rows through 1 KB of LDS.
 //
 // THREE WAVES per four bins.  The elimination of V_s does not depend on the chain through the sources -- only its right-hand
-// side u does -- so it is split off: waves 1 and 2 (sources of even / odd number) add the frame splits' partial covariances
-// (loaded straight into registers, a source ahead), eliminate V_s with the multipliers A[i][k] / A[k][k] RECORDED, and hand
-// the lanes' 16 multipliers + reciprocal pivot to wave 0 through LDS (17 KB per source, two buffers, two flag words each
-// way); wave 0 inverts W_hat^H, then per source applies the recorded row operations to u (64 multiply-adds), forms y,
-// updates C and stores the new row of W_hat.  Same operations on the same numbers as one wave doing all of it in turn.
+// side u does -- so it is split off: waves 1 and 2 (each takes the next source nobody has, from a counter) add the frame splits'
+// partial covariances (loaded straight into registers, a source ahead; float64, or -- opt-in -- the float32 blocks of the
+// matrix-core covariance kernel), eliminate V_s with the multipliers A[i][k] / A[k][k] RECORDED, and hand the lanes' 16
+// multipliers + reciprocal pivot to wave 0 through LDS (17 KB per source, three buffers, a flag word each way per buffer);
+// wave 0 inverts W_hat^H (a loop of four steps: sixteen unrolled ones were bound by instruction fetch), then per source
+// applies the recorded row operations to u (64 multiply-adds), forms y, updates C and stores the new row of W_hat.  Same
+// operations on the same numbers as one wave doing all of it in turn.  142 -> 59 us at 2048 bins; 46 us of that is reading the
+// 277 MB of float64 partials.
 #include "oiva_device.h"
 
 #include <cstdint>
@@ -35,7 +38,7 @@ namespace {
 
 constexpr int N = 16;
 constexpr int kBinsPerWaveR = 4;
-constexpr int kMaxSplitsR = 4;      // frame splits staged in LDS (more: the one-matrix-per-wave kernel)
+constexpr int kMaxSplitsR = 4;      // frame splits the eliminating waves add, two in flight at a time (more: the one-matrix-per-wave kernel)
 
 struct alignas(16) Z {       // (16-byte alignment: one ds_read_b128 / ds_write_b128 with a 16-bit immediate offset per value in LDS)
     double re, im;
