@@ -190,8 +190,13 @@ __global__ __launch_bounds__(kBlock, 2) void power_lds_kernel(const float2* __re
 
     // step s = (sub-batch sb = s / kPlTiles, tile tl = s % kPlTiles): rows = frames t0 + 16 tl + r, r < 16; this wave requests rows
     // 4 wave .. 4 wave + 3, each as two 1 KB halves (64 lanes x 16 bytes)
+    // The four sub-batches are taken in an order rotated by the workgroup's index.  All workgroups of a launch move at the same
+    // pace; with the same order everywhere, the chip asks memory for 2 KB of every 8 KB at any one time and the stream stops at
+    // 5.3 TB/s -- rotated, the workgroups in flight cover all four quarters: 6.3 TB/s for the stream alone
+    // (tools/r6/dmabench.hip, rows F and M).
+    const int rot = (blockIdx.x + blockIdx.y) & 3;
     auto issue = [&](int s, int buf) {
-        const int sb = s / kPlTiles, tl = s % kPlTiles;
+        const int sb = (s / kPlTiles + rot) & 3, tl = s % kPlTiles;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int r = 4 * wave + rr;
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(kBlock, 2) void power_lds_kernel(const float2* __re
     const unsigned rd_base = (unsigned)(uintptr_t)(&stage[0][0]) + j * kPlPitch + wave * 4 * 128 + q * 32;
     issue(0, 0);
     float2 w[4][4];                      // [bin of the wave][channel 4q + c]: W[f][m][k = j]
-    for (int sb = 0; sb < 4; ++sb) {
+    for (int sbi = 0; sbi < 4; ++sbi) {
+        const int sb = (sbi + rot) & 3;
         // W of this wave's four bins of the sub-batch (from L2; once per four steps).  Requested BEFORE the DMAs of the next
         // step, so that the counted wait below covers it.
 #pragma unroll
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(kBlock, 2) void power_lds_kernel(const float2* __re
             }
         static_for<kPlTiles>([&](auto tc) {
             constexpr int tl = decltype(tc)::value;
-            const int s = kPlTiles * sb + tl;
+            const int s = kPlTiles * sbi + tl;
             // buffer (s + 1) & 1 was read in step s - 1 and every wave has passed that step's second barrier
             if (s + 1 < kPlSteps) issue(s + 1, (s + 1) & 1);
             // this wave's eight requests of step s have landed (those of s + 1 -- and nothing else -- may still be in flight),
