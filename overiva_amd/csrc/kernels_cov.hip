@@ -268,6 +268,12 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
         }
         float4 v[PIECES];
         ring_read<PIECES>(rd_base + s * STAGE * 16, v);
+#if defined(OIVA_COVDMA_ABLATE) && (OIVA_COVDMA_ABLATE & 1)      // variant build (tools/build_variant.py): no arithmetic
+        if constexpr (kPacked) {
+            if (v[0].x == 12345.f) pacc.add(reinterpret_cast<const v2f(&)[M]>(v), v2f{w[0], w[1]});
+            return;
+        }
+#endif
         if constexpr (kPacked) {
             v2f x[M];
 #pragma unroll
@@ -298,7 +304,11 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
         const int k = k0 + kk;
         ginv[kk] = 1.f;
         if (raw & 1) continue;              // test hook: R holds the final reciprocal weights
+#if defined(OIVA_COVDMA_ABLATE) && (OIVA_COVDMA_ABLATE & 4)      // variant build: no sum over the frames in the prologue
+        const float gamma = R[k < K ? k : K - 1] + 1.f;
+#else
         const float gamma = (float)gamma_of(R, T, K, k < K ? k : K - 1);
+#endif
         ginv[kk] = 1.f / gamma;
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && k < K && wscale != nullptr)
             wscale[k] = model == OIVA_MODEL_LAPLACE ? gamma : sqrtf(gamma);   // overiva.py:163 / :167
@@ -317,6 +327,12 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
     if (i + 2 < nsteps) { issue(i + 5, 1); consume(i + 2, 2); }
     // drain the DMA queue before the ring is reused as reduction scratch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if defined(OIVA_COVDMA_ABLATE) && (OIVA_COVDMA_ABLATE & 2)      // variant build: no epilogue
+    if constexpr (kPacked) {
+        if (pacc.at(0) == 12345.f) Vpart[0] = 1.;
+        return;
+    }
+#endif
     // (adding the 4 phases of a wave in registers first -- v_permlane16/32_swap, a quarter of the LDS traffic, 4
     // barriers instead of 16 -- was measured slower: 102-104 us against 96-98)
     if constexpr (kPacked)
