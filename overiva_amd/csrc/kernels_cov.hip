@@ -196,6 +196,19 @@ __device__ __forceinline__ void ring_read<2>(unsigned addr, float4 (&v)[2]) {
         : "memory");
 }
 
+// (tools/build_variant.py ... -DOIVA_COVDMA_TRACE: 100 MHz wall-clock stamps of every workgroup, read by tools/r6/covdma_trace.py)
+#ifdef OIVA_COVDMA_TRACE
+__device__ long long g_cd_trace[8 * 2048];
+#define CD_STAMP(slot)                                                                                                            \
+    do {                                                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.z == 0) g_cd_trace[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define CD_STAMP(slot) \
+    do {               \
+    } while (0)
+#endif
+
 template <int M, int KC>
 __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __restrict__ X, const float* __restrict__ R,
                                                             float* __restrict__ wscale, int model, int raw,
@@ -295,6 +308,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
         }
     };
 
+    CD_STAMP(0);
     issue(0, 0);
     issue(1, 1);
     issue(2, 2);
@@ -314,6 +328,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
             wscale[k] = model == OIVA_MODEL_LAPLACE ? gamma : sqrtf(gamma);   // overiva.py:163 / :167
     }
 
+    CD_STAMP(1);
     int i = 0;
     for (; i + 4 <= nsteps; i += 4) {       // stage indices are compile-time constants in the unrolled body
         issue(i + 3, 3); consume(i, 0);
@@ -325,8 +340,10 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
     if (i < nsteps) { issue(i + 3, 3); consume(i, 0); }
     if (i + 1 < nsteps) { issue(i + 4, 0); consume(i + 1, 1); }
     if (i + 2 < nsteps) { issue(i + 5, 1); consume(i + 2, 2); }
+    CD_STAMP(2);
     // drain the DMA queue before the ring is reused as reduction scratch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CD_STAMP(3);
 #if defined(OIVA_COVDMA_ABLATE) && (OIVA_COVDMA_ABLATE & 2)      // variant build: no epilogue
     if constexpr (kPacked) {
         if (pacc.at(0) == 12345.f) Vpart[0] = 1.;
@@ -339,6 +356,7 @@ __global__ __launch_bounds__(kBlock, 2) void cov_dma_kernel(const float2* __rest
         reduce_and_store_at<M, KC, float>([&](int e) { return pacc.at(e); }, reinterpret_cast<float*>(ring), Vpart, F, K, k0);
     else
         reduce_and_store<M, KC, float>(acc, reinterpret_cast<float*>(ring), Vpart, F, K, k0);
+    CD_STAMP(4);
 }
 
 template <typename ACC>
@@ -478,5 +496,9 @@ hipError_t cov_blocks_per_cu(int M, int kc, bool f64, int* n) {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, kern, kBlock, 0);
     });
 }
+
+#ifdef OIVA_COVDMA_TRACE
+extern "C" int oiva_debug_covdma_trace(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cd_trace), sizeof(g_cd_trace)); }
+#endif
 
 }  // namespace oiva
