@@ -162,8 +162,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 //   |y|^2 summed over the wave's bins in the accumulator layout, over the four waves through LDS at the end: the same
 //   64-bin parts as every other power kernel.
 // Round 5, measured by ablation at 2048 x 4000 x 16 / 16 (220 us): without the matrix instructions (DMAs, barriers, LDS reads)
-// 202 us -- with ONE workgroup per CU instead of two still 204, so it is not the bytes in flight that bound the stream of 2 KB
-// runs but the stream itself (5.2 TB/s) --, without the DMAs 145 us: the two overlap to within 18 us.
+// 202 us -- with ONE workgroup per CU instead of two still 204, so it is not the bytes in flight that bound the stream --, without
+// the DMAs 145 us: the two overlap to within 18 us.  Round 6: what bound the stream at 5.2 TB/s was the ORDER of the sub-batches,
+// the same in every workgroup (see `rot` below): rotated, the stream alone runs at 6.3 TB/s (165 us) and the kernel in 193 us.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPlTiles = 4;                          // frame tiles of 16 per workgroup
 constexpr int kPlFrames = 16 * kPlTiles;
