@@ -150,12 +150,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same product with X staged through LDS (16 channels, whole 64-bin batches).  power_mfma_kernel asks memory for 128-byte
+// The same product with X staged through LDS (16 channels, 64-bin batches; the last batch may be ragged, F >= 64).  power_mfma_kernel asks memory for 128-byte
 // runs 262 KB apart (lane = frame: 16 frames x one bin per load instruction) and reaches 0.56 of the HBM peak; the vector-ALU
 // power_kernel<16, 2>, whose loads are 2 KB runs (lane = bin), moves the same bytes at 0.74.  Here the loads are those 2 KB
 // runs -- one frame's 16 bins x 16 channels, by LDS-DMA, no staging registers -- and the matrix cores read their frame-major
 // operands back from LDS:
-//   workgroup = one 64-bin batch x kPlFrames frames; steps = 4 sub-batches of 16 bins x kPlTiles tiles of 16 frames;
+//   workgroup = one 64-bin batch x kPlFrames frames; steps = (up to) 4 sub-batches of 16 bins x kPlTiles tiles of 16 frames;
 //   a step: 16 rows of 2 KB -> LDS (pitch 2 KB + 16 bytes: lane (frame j, quarter q) reads 32 bytes at row j -- the 16 frames
 //   of a read pass fall into 16 different bank groups); wave w multiplies bins 4w .. 4w + 3 of the sub-batch (W of its four
 //   bins in registers for the sub-batch's four steps); two buffers, the DMA of step s + 1 in flight behind the products of s;
@@ -168,7 +168,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPlTiles = 4;                          // frame tiles of 16 per workgroup
 constexpr int kPlFrames = 16 * kPlTiles;
-constexpr int kPlSteps = 4 * kPlTiles;              // 4 sub-batches of 16 bins x the tiles
 constexpr int kPlRow = 16 * 16 * 8;                  // one frame's 16 bins x 16 channels
 constexpr int kPlPitch = kPlRow + 16;
 constexpr int kPlStage = 16 * kPlPitch;              // bytes per buffer
@@ -195,14 +194,23 @@ __global__ __launch_bounds__(kBlock, 2) void power_lds_kernel(const float2* __re
     // pace; with the same order everywhere, the chip asks memory for 2 KB of every 8 KB at any one time and the stream stops at
     // 5.3 TB/s -- rotated, the workgroups in flight cover all four quarters: 6.3 TB/s for the stream alone
     // (tools/r6/dmabench.hip, rows F and M).
-    const int rot = (blockIdx.x + blockIdx.y) & 3;
+    // (a ragged last batch has fewer sub-batches: those that start past the last bin are left out, one that is cut is shifted below)
+    const int nsb = min(4, (F - f0 + 15) >> 4);
+    const int nsteps = nsb * kPlTiles;
+    const int rot = (int)((blockIdx.x + blockIdx.y) % (unsigned)nsb);
+    auto sub_batch = [&](int sbi) {
+        const int sb = sbi + rot;
+        return sb < nsb ? sb : sb - nsb;
+    };
     auto issue = [&](int s, int buf) {
-        const int sb = (s / kPlTiles + rot) & 3, tl = s % kPlTiles;
+        const int sb = sub_batch(s / kPlTiles), tl = s % kPlTiles;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int r = 4 * wave + rr;
             const int t = t0 + 16 * tl + r;
-            const float2* src = X + (size_t)(t < T ? t : T - 1) * frame_stride + (size_t)(f0 + 16 * sb) * M;   // (frames past T: a valid row, never stored)
+            // (frames past T: a valid row, never stored; a sub-batch that would run past the last bin starts at bin F - 16 instead and
+            //  the bins it then holds twice meet a zero in W below)
+            const float2* src = X + (size_t)(t < T ? t : T - 1) * frame_stride + (size_t)min(f0 + 16 * sb, F - 16) * M;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
                 __builtin_amdgcn_global_load_lds((gvoid_pl_t*)(src + h * 128 + lane * 2), (lvoid_pl_t*)(stage[buf] + r * kPlPitch + h * 1024), 16, 0, 0);
@@ -218,25 +226,28 @@ __global__ __launch_bounds__(kBlock, 2) void power_lds_kernel(const float2* __re
     const unsigned rd_base = (unsigned)(uintptr_t)(&stage[0][0]) + j * kPlPitch + wave * 4 * 128 + q * 32;
     issue(0, 0);
     float2 w[4][4];                      // [bin of the wave][channel 4q + c]: W[f][m][k = j]
-    for (int sbi = 0; sbi < 4; ++sbi) {
-        const int sb = (sbi + rot) & 3;
+    for (int sbi = 0; sbi < nsb; ++sbi) {
+        const int sb = sub_batch(sbi);
         // W of this wave's four bins of the sub-batch (from L2; once per four steps).  Requested BEFORE the DMAs of the next
         // step, so that the counted wait below covers it.
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float2 wv = What[((size_t)(f0 + 16 * sb + 4 * wave + g) * M + 4 * q + c) * M + (j < K ? j : 0)];
-                w[g][c] = make_float2(j < K ? wv.x : 0.f, j < K ? wv.y : 0.f);
+                const int first = f0 + 16 * sb;                                  // the sub-batch's own bins start here ...
+                const int bin = min(first, F - 16) + 4 * wave + g;               // ... the run in LDS may start earlier (ragged last batch)
+                const bool ok = j < K && bin >= first;
+                const float2 wv = What[((size_t)bin * M + 4 * q + c) * M + (j < K ? j : 0)];
+                w[g][c] = make_float2(ok ? wv.x : 0.f, ok ? wv.y : 0.f);
             }
         static_for<kPlTiles>([&](auto tc) {
             constexpr int tl = decltype(tc)::value;
             const int s = kPlTiles * sbi + tl;
             // buffer (s + 1) & 1 was read in step s - 1 and every wave has passed that step's second barrier
-            if (s + 1 < kPlSteps) issue(s + 1, (s + 1) & 1);
+            if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
             // this wave's eight requests of step s have landed (those of s + 1 -- and nothing else -- may still be in flight),
             // then every wave's.  Raw barrier: __syncthreads() carries a release fence, which drains the DMA queue.
-            if (s + 1 < kPlSteps)
+            if (s + 1 < nsteps)
                 asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -325,10 +336,10 @@ hipError_t launch_power_mfma(hipStream_t s, const float2* X, const float2* What,
     // measured at 2048 x 4000 x 16 / 16 (tiles x bins per group): 4x1 252 us, 2x1 252, 2x2 267, 1x2 279, 1x4 306 -- the
     // W operands come from L2 once per wave and bin, so more frames per wave is less W traffic (W-only 81 us at 1x4);
     // X alone streams in 199 us, the MFMAs alone take 134 us
-    // 16 channels, whole 64-bin batches: X staged through LDS in 2 KB runs (power_lds_kernel above); $OIVA_POWER_LDS=0: off
+    // 16 channels, at least 64 bins: X staged through LDS in 2 KB runs (power_lds_kernel above); $OIVA_POWER_LDS=0: off
     static const bool lds = [] { const char* v = getenv("OIVA_POWER_LDS"); return !(v && v[0] == '0'); }();
-    if (lds && M == 16 && Mp == 16 && F % kBinsPerBatch == 0 && T >= 16) {
-        power_lds_kernel<<<dim3(F / kBinsPerBatch, (T + kPlFrames - 1) / kPlFrames), dim3(kBlock), 0, s>>>(X, What, Ppart, T, F, K);
+    if (lds && M == 16 && Mp == 16 && F >= kBinsPerBatch && T >= 16) {
+        power_lds_kernel<<<dim3((F + kBinsPerBatch - 1) / kBinsPerBatch, (T + kPlFrames - 1) / kPlFrames), dim3(kBlock), 0, s>>>(X, What, Ppart, T, F, K);
         return hipGetLastError();
     }
     return launch_shape<4, 1>(s, X, What, Ppart, T, F, M, Mp, K);

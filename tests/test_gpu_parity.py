@@ -195,10 +195,11 @@ def test_power_pass_of_many_sources_at_every_channel_count(oa, shape, before_cov
 @pytest.mark.parametrize("shape", [(100, 64, 16, 16), (64, 128, 16, 9), (37, 64, 16, 5), (16, 64, 16, 16), (1000, 192, 16, 13), (129, 64, 16, 8)],
                          ids=lambda s: "x".join(str(v) for v in s))
 def test_power_pass_through_lds_at_16_channels(oa, shape):
-    """power_lds_kernel (16 channels, more than 4 sources, whole 64-bin batches; overiva.py:140 + :153): X in 2 KB runs through
+    """power_lds_kernel (16 channels, more than 4 sources, at least 64 bins; overiva.py:140 + :153): X in 2 KB runs through
     LDS to the matrix cores -- frame counts that are no multiple of the 64 frames of a workgroup or the 16 of a tile, every
-    source count, several batches; against the oracle and against the kernel it replaces ($OIVA_POWER_LDS=0 is read once per
-    process, so the other kernel is reached through a bin count that is no multiple of 64: the same bins plus one)"""
+    source count, several batches, whole batches (F bins) and a ragged last batch of ONE bin (F + 1 bins: its one sub-batch
+    starts at bin F - 15 and the bins it then holds twice meet a zero in W); against the oracle, and the two against each
+    other through the last bin's own contribution"""
     T, F, M, K = shape
     X = orc.synth_iid(T, F + 1, M, seed=3)
     rng = np.random.default_rng(6)
@@ -209,7 +210,7 @@ def test_power_pass_through_lds_at_16_channels(oa, shape):
         p.t_set_what(What[:F])
         pw = p.t_run_power()
     assert orc.rel_err(pw, orc.demix_power(X[:, :F], What[:F, :, :K])) < TOL_KERNEL
-    with oa.Plan(T, F + 1, M, K, "laplace") as p:          # the frame-major kernel (F + 1 bins: no whole batches)
+    with oa.Plan(T, F + 1, M, K, "laplace") as p:
         p.set_x(X)
         p.covariance()
         p.t_set_what(What)
@@ -219,6 +220,31 @@ def test_power_pass_through_lds_at_16_channels(oa, shape):
     # the last bin's own contribution, from the oracle, takes one result to the other
     last = orc.demix_power(X[:, F:], What[F:, :, :K])
     assert orc.rel_err(pw1 - last, pw) < 2 * TOL_KERNEL
+
+
+@pytest.mark.parametrize("shape", [(70, 65, 16, 16), (33, 79, 16, 7), (50, 80, 16, 16), (40, 111, 16, 9), (64, 127, 16, 16), (20, 190, 16, 12), (48, 63, 16, 16), (48, 17, 16, 6)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+def test_power_pass_ragged_last_batch_at_16_channels(oa, shape):
+    """a last batch of 1, 15, 16, 47, 63 bins (and two batches + 62) through power_lds_kernel -- sub-batches that are whole,
+    cut, or past the last bin; fewer than 64 bins: the frame-major kernel (power_mfma_kernel) -- each bin's power with the
+    other bins' W set to zero must be that bin's alone: a bin counted twice or not at all shows as a factor, not as rounding
+    (overiva.py:140 + :153)"""
+    T, F, M, K = shape
+    X = orc.synth_iid(T, F, M, seed=5)
+    rng = np.random.default_rng(8)
+    What = (rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M))).astype(np.complex64)
+    with oa.Plan(T, F, M, K, "laplace") as p:
+        p.set_x(X)
+        p.covariance()
+        p.t_set_what(What)
+        pw = p.t_run_power()
+        assert orc.rel_err(pw, orc.demix_power(X, What[:, :, :K])) < TOL_KERNEL
+        for f in sorted({0, 15, 16, F - 17, F - 16, F - 15, F - 2, F - 1, (F // 64) * 64, (F // 64) * 64 - 1} & set(range(F))):
+            W1 = np.zeros_like(What)
+            W1[f] = What[f]
+            p.t_set_what(W1)
+            one = p.t_run_power()
+            assert orc.rel_err(one, orc.demix_power(X[:, f:f + 1], What[f:f + 1, :, :K])) < TOL_KERNEL, f
 
 
 @pytest.mark.needs("im_{model}_e0_s0_V")
@@ -869,7 +895,7 @@ def test_cfg5_shape_full_frame_axis(oa, mode):
     """BASELINE.json configs[4] shape at full T with few bins: 8 bins x 4000 frames x 16 mics / 16 src, in every arithmetic
     -- `mixed` is what bench.py times and overiva() runs on it: cov_hmfma_kernel<true> (all 16 sources on the fp32 matrix
     cores, Hermitian products from LDS partners, float32 chains over the frame splits, float64 partials), the matrix-core
-    power pass of > 4 sources (8 bins: power_mfma_kernel; whole 64-bin batches: power_lds_kernel) and update_det16r_kernel
+    power pass of > 4 sources (8 bins: power_mfma_kernel; 64 bins or more: power_lds_kernel) and update_det16r_kernel
     (w = V_s^-1 u by one elimination per source with recorded multipliers, C = (W_hat^H)^-1 kept by rank-one steps);
     `precise`: cov_hmfma64_kernel (the same GEMM on the fp64 matrix cores); `fast`: float32 per-bin algebra"""
     T, F, M, K = 4000, 8, 16, 16
