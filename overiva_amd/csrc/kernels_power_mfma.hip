@@ -150,8 +150,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same product with X staged through LDS (16 channels, 64-bin batches; the last batch may be ragged, F >= 64).  power_mfma_kernel asks memory for 128-byte
-// runs 262 KB apart (lane = frame: 16 frames x one bin per load instruction) and reaches 0.56 of the HBM peak; the vector-ALU
+// The same product with X staged through LDS (16 channels, 64-bin batches; the last batch may be ragged, F >= 64).
+// power_mfma_kernel asks memory for 128-byte runs 262 KB apart (lane = frame: 16 frames x one bin per load instruction) and reaches 0.56 of the HBM peak; the vector-ALU
 // power_kernel<16, 2>, whose loads are 2 KB runs (lane = bin), moves the same bytes at 0.74.  Here the loads are those 2 KB
 // runs -- one frame's 16 bins x 16 channels, by LDS-DMA, no staging registers -- and the matrix cores read their frame-major
 // operands back from LDS:
